@@ -1,0 +1,287 @@
+"""CPU restatement of the UmeTrack network.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Functional torch-CPU code driven
+directly by a ``state_dict``; no ``nn.Module``.  ``dtype=torch.float64`` runs the
+same graph in double precision and serves as the "truth" against which both the
+reference's fp32 result and the HIP fp32 result are measured.
+
+Pinned: tests/test_oracle_model.py checks every function here against
+tests/golden/model_*.npz, which tests/golden/make_goldens.py produced by
+importing the reference's lib.models with the same seeded weights.
+"""
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from umetrack_amd import arch
+
+_BB = "_feature_extractor._image_backbone"
+_FUSE = "_feature_extractor._multi_view_fusion"
+_TEMP = "_temporal._temporal_module"
+_SKEL = "_skeleton_enc._layers"
+
+
+def to_torch_state(sd, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in sd.items():
+        t = torch.as_tensor(np.asarray(v)) if not isinstance(v, torch.Tensor) else v
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out
+
+
+def _bn(x, sd, p):
+    # eval-mode BatchNorm2d: running statistics (umetrack_model.py:117 -> .eval())
+    return F.batch_norm(x, sd[f"{p}.running_mean"], sd[f"{p}.running_var"],
+                        sd[f"{p}.weight"], sd[f"{p}.bias"], False, 0.0, arch.BN_EPS)
+
+
+def _basic_block(x, sd, p, stride):
+    # backbone_resnet.py:56-72
+    out = F.conv2d(x, sd[f"{p}.conv1.weight"], None, stride, 1)
+    out = F.relu(_bn(out, sd, f"{p}.bn1"))
+    out = F.conv2d(out, sd[f"{p}.conv2.weight"], None, 1, 1)
+    out = _bn(out, sd, f"{p}.bn2")
+    if f"{p}.downsample.0.weight" in sd:
+        x = _bn(F.conv2d(x, sd[f"{p}.downsample.0.weight"], None, stride, 0),
+                sd, f"{p}.downsample.1")
+    return F.relu(out + x)
+
+
+def backbone(sd, images: torch.Tensor) -> torch.Tensor:
+    """(n,96,96) -> (n,72,6,6).  model_utils.py:107-138, backbone_resnet.py:155-158."""
+    x = images.unsqueeze(1)
+    x = F.conv2d(x, sd[f"{_BB}.0._layers.0.0.weight"], sd[f"{_BB}.0._layers.0.0.bias"], 1, 1)
+    x = F.max_pool2d(F.relu(_bn(x, sd, f"{_BB}.0._layers.0.1")), 2, 2)
+    for si, ((_, _, stride), nblk) in enumerate(zip(arch.stage_planes(), arch.STAGE_BLOCKS), 1):
+        for b in range(nblk):
+            x = _basic_block(x, sd, f"{_BB}.0._layers.{si}.{b}", stride if b == 0 else 1)
+    return F.conv2d(x, sd[f"{_BB}.1.weight"], sd[f"{_BB}.1.bias"])
+
+
+def ftl(xfs: torch.Tensor, fmap: torch.Tensor) -> torch.Tensor:
+    """model_utils.py:57-104 with ratio 1.0: channel thirds are X/Y/Z."""
+    n = fmap.shape[0]
+    pts = fmap.reshape(n, 3, -1)
+    pts = xfs[:, :3, :3] @ pts + xfs[:, :3, 3:4]
+    return pts.reshape(fmap.shape)
+
+
+def singlev_xfs(intrinsics: torch.Tensor) -> torch.Tensor:
+    """model_utils.py:166-192: S = diag(1, 1, fx/200, 1)."""
+    s = torch.eye(4, dtype=intrinsics.dtype).repeat(intrinsics.shape[0], 1, 1)
+    s[:, 2, 2] = intrinsics[:, 0, 0] / 200
+    return s
+
+
+def _fusion_convs(sd, x):
+    x = F.relu(_bn(F.conv2d(x, sd[f"{_FUSE}.0.weight"], sd[f"{_FUSE}.0.bias"]), sd, f"{_FUSE}.1"))
+    x = F.relu(_bn(F.conv2d(x, sd[f"{_FUSE}.3.weight"], sd[f"{_FUSE}.3.bias"]), sd, f"{_FUSE}.4"))
+    return F.conv2d(x, sd[f"{_FUSE}.6.weight"], sd[f"{_FUSE}.6.bias"])
+
+
+def fuse_two_views(sd, feats, s_xf, ext):
+    """feature_extractor.py:61-141 (useUnscaledAsCanonical=False).
+
+    feats (b,2,72,6,6), s_xf (b,2,4,4), ext (b,2,4,4) -> (b,72,6,6)
+    """
+    to_world = torch.inverse(ext) @ s_xf
+    to_canon = torch.inverse(s_xf[:, 0:1]) @ ext[:, 0:1] @ to_world
+    canon = ftl(to_canon.reshape(-1, 4, 4), feats.flatten(0, 1)).reshape(feats.shape)
+    fused = _fusion_convs(sd, canon.flatten(1, 2))
+    return ftl(s_xf[:, 0], fused)
+
+
+def fuse_views(sd, per_view, intrinsics, extrinsics, sample_range) -> torch.Tensor:
+    """umetrack_model.py:123-168, both the all-2-view path and the ragged loop."""
+    s_xf = singlev_xfs(intrinsics)
+    bs = sample_range.shape[0]
+    if bs * 2 == per_view.shape[0]:
+        return fuse_two_views(sd, per_view.reshape(bs, 2, *per_view.shape[1:]),
+                              s_xf.reshape(bs, 2, 4, 4), extrinsics.reshape(bs, 2, 4, 4))
+    rows = []
+    for r0, r1 in np.asarray(sample_range).tolist():
+        if r1 - r0 == 1:
+            rows.append(ftl(s_xf[r0:r1], per_view[r0:r1]))      # fusion convs skipped
+        else:
+            rows.append(fuse_two_views(sd, per_view[r0:r1][None], s_xf[r0:r1][None],
+                                       extrinsics[r0:r1][None]))
+    return torch.cat(rows, 0)
+
+
+class TemporalState:
+    """temporal.py:41-42, 93-139: memory rows and previous cam0 extrinsics."""
+
+    def __init__(self):
+        self.mem = torch.empty(0)
+        self.prev = torch.empty(0)
+
+
+def temporal_step(sd, state: TemporalState, img_feat, cur_ext, memory_idx, use_memory):
+    """SimpleConvRNN.forward_temporal_features (temporal.py:51-139)."""
+    dt = img_feat.dtype
+    need = int(memory_idx.max()) + 1
+    mem, prev = state.mem, state.prev
+    if mem.shape[0] < need:
+        nm = torch.zeros(need, arch.N_MEM, *img_feat.shape[-2:], dtype=dt)
+        npv = torch.zeros(need, 4, 4, dtype=dt)
+        if mem.shape[0]:
+            nm[: mem.shape[0]] = mem
+            npv[: prev.shape[0]] = prev
+        mem, prev = nm, npv
+    use_idx = memory_idx[use_memory]
+    if len(use_idx) != len(use_memory):
+        zi = memory_idx[~use_memory]
+        mem[zi] = 0
+        prev[zi] = 0
+    if len(use_idx):
+        rel = cur_ext[use_memory].bmm(torch.inverse(prev[use_idx]))
+        mem[use_idx] = ftl(rel, mem[use_idx])
+    prev[memory_idx] = cur_ext
+    x = torch.cat([mem[memory_idx], img_feat], 1)
+    x = F.relu(F.conv2d(x, sd[f"{_TEMP}.0.weight"], sd[f"{_TEMP}.0.bias"]))
+    x = F.relu(F.conv2d(x, sd[f"{_TEMP}.2.weight"], sd[f"{_TEMP}.2.bias"]))
+    x = F.conv2d(x, sd[f"{_TEMP}.4.weight"], sd[f"{_TEMP}.4.bias"])
+    mem[memory_idx] = x[:, : arch.N_MEM]
+    state.mem, state.prev = mem, prev
+    return x[:, arch.N_MEM:]
+
+
+def skeleton_features(sd, axes, rest) -> torch.Tensor:
+    """skeleton_encoder.py:43-53: (...,22,3)x2 -> (numel,4,6,6)."""
+    x = torch.cat((axes, rest), -1).reshape(-1, 132)
+    x = F.linear(x, sd[f"{_SKEL}.0.weight"], sd[f"{_SKEL}.0.bias"])
+    x = x.view(-1, arch.N_SKEL_FEAT, arch.FEAT_HW, arch.FEAT_HW)
+    return F.relu(_bn(x, sd, f"{_SKEL}.2"))
+
+
+def rigid_source_points(dtype=torch.float32) -> torch.Tensor:
+    """regressor.py:19-47: seven fixed points, non-zero ones rescaled to norm 0.1."""
+    p = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1],
+                  [-1, -1, 0], [-1, 0, -1], [0, -1, -1]], dtype=np.float64)
+    nrm = np.linalg.norm(p, axis=1, keepdims=True)
+    p = np.where(nrm > 0, p / np.maximum(nrm, 1e-300) * 0.1, p)
+    return torch.from_numpy(p.astype(np.float32)).to(dtype)
+
+
+def procrustes(from_pts, to_pts) -> torch.Tensor:
+    """model_utils.py:17-54 (Kabsch with the reflection fix)."""
+    b = from_pts.shape[0]
+    fm, tm = from_pts.mean(1), to_pts.mean(1)
+    h = (from_pts - fm[:, None]).transpose(1, 2) @ (to_pts - tm[:, None])
+    u, _, vh = torch.linalg.svd(h)
+    v = vh.transpose(1, 2)
+    d = torch.det(v @ u.transpose(1, 2))
+    w = torch.eye(3, dtype=from_pts.dtype).repeat(b, 1, 1)
+    w[:, 2, 2] = d
+    xf = torch.eye(4, dtype=from_pts.dtype).repeat(b, 1, 1)
+    xf[:, :3, :3] = v @ w @ u.transpose(1, 2)
+    xf[:, :3, 3] = tm - (xf[:, :3, :3] @ fm[..., None])[..., 0]
+    return xf
+
+
+def regress_raw(sd, head: str, x) -> torch.Tensor:
+    """model_utils.py:195-208: 2 BasicBlocks, conv1x1, global average pool."""
+    p = f"{head}._pose_regression_layers"
+    x = _basic_block(x, sd, f"{p}.0", 1)
+    x = _basic_block(x, sd, f"{p}.1", 1)
+    x = F.conv2d(x, sd[f"{p}.2.weight"], sd[f"{p}.2.bias"])
+    return x.mean((2, 3))
+
+
+def decode(raw, predict_scale: bool) -> Dict[str, torch.Tensor]:
+    """regressor.py:76-121, 163-186."""
+    sl = arch.regressor_slices(predict_scale)
+    out = {}
+    a0, a1 = sl["joint_angles"]
+    out["joint_angles"] = torch.cat([raw[:, a0:a1], raw.new_zeros(raw.shape[0], 2)], 1)
+    w0, w1 = sl["wrist_xfs"]
+    pts = raw[:, w0:w1].reshape(raw.shape[0], -1, 3)
+    src = rigid_source_points(raw.dtype)[None].expand(raw.shape[0], -1, -1)
+    out["wrist_xfs"] = procrustes(src, pts)
+    if predict_scale:
+        s0, s1 = sl["skel_scales"]
+        out["skel_scales"] = torch.exp(raw[:, s0:s1].reshape(-1))
+    u0, u1 = sl["landmark_uncertainty_sigmas"]
+    out["landmark_uncertainty_sigmas"] = torch.clamp(F.softplus(raw[:, u0:u1]), min=1e-5)
+    return out
+
+
+def wrist_in_world(hand_idx, cam0_ext, wrist_cam0) -> torch.Tensor:
+    """umetrack_model.py:77-90."""
+    w = torch.inverse(cam0_ext) @ wrist_cam0
+    w = w.clone()
+    w[hand_idx == 1, :, 0] *= -1
+    return w
+
+
+class OracleModel:
+    """Same call surface as UmeTrackModel (umetrack_model.py:100-242), CPU only."""
+
+    def __init__(self, state, dtype=torch.float32):
+        self.dtype = dtype
+        self.sd = to_torch_state(state, dtype)
+        self.state = TemporalState()
+        self.last: Dict[str, torch.Tensor] = {}     # intermediates, for stage-level tests
+
+    def _c(self, t):
+        return t.detach().cpu().to(self.dtype)
+
+    def _features(self, fd, desc):
+        images, K, E = self._c(fd.left_images), self._c(fd.intrinsics), self._c(fd.extrinsics_xf)
+        sr = desc.sample_range.cpu().long()
+        per_view = backbone(self.sd, images)
+        fused = fuse_views(self.sd, per_view, K, E, sr)
+        cam0 = E[sr[:, 0]]
+        temporal = temporal_step(self.sd, self.state, fused, cam0,
+                                 desc.memory_idx.cpu().long(), desc.use_memory.cpu().bool())
+        self.last.update(per_view=per_view, fused=fused, temporal=temporal,
+                         memory=self.state.mem.clone())
+        return temporal, cam0
+
+    def regress_pose_use_skeleton(self, fd, desc, skel):
+        temporal, cam0 = self._features(fd, desc)
+        sk = skeleton_features(self.sd, self._c(skel.joint_rotation_axes),
+                               self._c(skel.joint_rest_positions))
+        if sk.shape[0] == 1 and temporal.shape[0] > 1:
+            sk = sk.expand(temporal.shape[0], *sk.shape[1:])
+        raw = regress_raw(self.sd, "_regressor_k", torch.cat([temporal, sk], 1))
+        out = decode(raw, False)
+        out["wrist_xfs"] = wrist_in_world(desc.hand_idx.cpu().long(), cam0, out["wrist_xfs"])
+        self.last.update(raw=raw, skel=sk)
+        return out
+
+    def regress_pose_pred_skel_scale(self, fd, desc):
+        sr = desc.sample_range.cpu().long()
+        assert bool(((sr[:, 1] - sr[:, 0]) != 1).all()), \
+            "Unsupported: found single-view samples when calibration scale"
+        temporal, cam0 = self._features(fd, desc)
+        raw = regress_raw(self.sd, "_regressor_u", temporal)
+        out = decode(raw, True)
+        out["wrist_xfs"] = wrist_in_world(desc.hand_idx.cpu().long(), cam0, out["wrist_xfs"])
+        self.last.update(raw=raw)
+        return out
+
+
+# ---------------------------------------------------------------------------
+# Independent numpy fp64 convolution (im2col) used to cross-check F.conv2d on
+# small cases, so that the oracle does not rest on a single conv implementation.
+# ---------------------------------------------------------------------------
+def conv2d_numpy(x: np.ndarray, w: np.ndarray, bias: Optional[np.ndarray],
+                 stride: int, pad: int) -> np.ndarray:
+    n, c, h, wd = x.shape
+    co, ci, kh, kw = w.shape
+    assert ci == c
+    xp = np.zeros((n, c, h + 2 * pad, wd + 2 * pad), dtype=np.float64)
+    xp[:, :, pad:pad + h, pad:pad + wd] = x
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    cols = np.empty((n, c, kh, kw, ho, wo), dtype=np.float64)
+    for i in range(kh):
+        for j in range(kw):
+            cols[:, :, i, j] = xp[:, :, i:i + stride * ho:stride, j:j + stride * wo:stride]
+    y = np.einsum("ok,nkp->nop", w.reshape(co, -1).astype(np.float64),
+                  cols.reshape(n, c * kh * kw, ho * wo)).reshape(n, co, ho, wo)
+    if bias is not None:
+        y += bias.reshape(1, -1, 1, 1)
+    return y
