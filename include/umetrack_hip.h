@@ -1,0 +1,154 @@
+/*
+ * umetrack_hip.h - C ABI of libumetrack_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (facebookresearch/UmeTrack) is pure Python and has no FFI of its
+ * own.  Each entry point below therefore cites the Python
+ * call site it replaces; the Python host in umetrack_amd/lib/ keeps the
+ * reference's names and signatures and forwards to these functions via ctypes.
+ *
+ * Conventions
+ *  - every pointer marked "dev" is device memory on the device the model was
+ *    finalised on; the caller owns every input, output and workspace buffer;
+ *  - the library allocates device memory only in umt_model_finalize() (weights)
+ *    and umt_model_reserve_memory() (temporal state); stage calls never allocate;
+ *  - all work is enqueued on `stream` (a hipStream_t passed as void*); nothing
+ *    synchronises the host;
+ *  - return value 0 = ok, non-zero = error; umt_last_error() returns the
+ *    thread-local message of the last failing call;
+ *  - layouts at this boundary are the reference's (NCHW feature maps, row-major
+ *    4x4 transforms, int64 index tensors); the channels-last layout used between
+ *    kernels is private to the library.
+ */
+#ifndef UMETRACK_HIP_H
+#define UMETRACK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct umt_model umt_model;
+
+enum {
+  UMT_OK = 0,
+  UMT_ERR_INVALID = 1,     /* bad argument / shape */
+  UMT_ERR_STATE = 2,       /* call order (e.g. forward before finalize) */
+  UMT_ERR_KEY = 3,         /* strict state_dict mismatch */
+  UMT_ERR_HIP = 4,         /* a HIP runtime call failed */
+  UMT_ERR_WORKSPACE = 5,   /* workspace too small */
+  UMT_ERR_UNSUPPORTED = 6
+};
+
+enum { UMT_PREC_FP32 = 0, UMT_PREC_BF16 = 1 };
+enum { UMT_HEAD_KNOWN_SKELETON = 0, UMT_HEAD_PREDICT_SCALE = 1 };
+enum { UMT_WARP_CV2_FIXED_POINT = 0, UMT_WARP_FLOAT = 1 };
+
+const char* umt_last_error(void);
+int umt_abi_version(void);
+
+/* ---- model handle: replaces load_pretrained_model, lib/models/model_loader.py:53-88 ---- */
+int umt_model_create(umt_model** out);
+int umt_model_destroy(umt_model* m);
+/* the strict key table (== reference state_dict, 252 entries) */
+int umt_model_param_count(const umt_model* m, int* count);
+int umt_model_param_info(const umt_model* m, int index, const char** key, int* ndim,
+                         int64_t shape[4], int* is_int64);
+/* host data, float32 (or int64 for num_batches_tracked); copied */
+int umt_model_set_param(umt_model* m, const char* key, const void* host_data, int ndim,
+                        const int64_t* shape, int is_int64);
+/* strict check (every key set exactly once), weight packing, upload to `device` */
+int umt_model_finalize(umt_model* m, int device);
+/* temporal state: SimpleConvRNN._mem_features/_prev_extrinsics, lib/models/temporal.py:41-42,102-125 */
+int umt_model_reserve_memory(umt_model* m, int rows, void* stream);   /* grows, keeps content */
+int umt_model_memory_rows(const umt_model* m, int* rows);
+int umt_model_clear_memory(umt_model* m);                              /* back to 0 rows */
+/* copy state out for inspection: mem (rows,18,6,6), prev_ext (rows,4,4), both dev */
+int umt_model_read_memory(const umt_model* m, float* mem_dev, float* prev_ext_dev, void* stream);
+
+/* ---- workspace sizes (bytes) ---- */
+int64_t umt_backbone_workspace_bytes(int n_crops);
+int64_t umt_head_workspace_bytes(int n_crops, int n_samples);
+int64_t umt_forward_workspace_bytes(int n_crops, int n_samples);
+
+/* ---- A1: fisheye -> pinhole crop, _warp_image + /255, lib/tracker/tracker.py:54-80,210-211 ----
+ * src_images dev uint8; image i of crop k starts at src_images + src_offset[k] with row pitch
+ * src_pitch[k] (bytes) - this is how a 4-view-wide frame is addressed (video_pose_data.py:123-125).
+ * src_cams  dev float64 (n,30): w,h,fx,fy,cx,cy,k1,k2,k3,k4,p1,p2,k5,k6, cam_to_world 4x4 row-major
+ * dst_cams  dev float64 (n,20): fx,fy,cx,cy, cam_to_world 4x4 row-major (96x96 pinhole crop cameras)
+ * out       dev float32 (n,out_h,out_w), values in [0,1]                                            */
+int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offset, const int32_t* src_pitch,
+                   const double* src_cams, const double* dst_cams, int n, int out_h, int out_w,
+                   int mode, float* out, void* stream);
+
+/* ---- A1': pinhole -> pinhole float resample, _resample_images_batched,
+ * lib/batched_dataset/data_transform.py:78-144.  images dev f32 (n,h,w), xfs dev f32 (n,4,4),
+ * out dev f32 (n,out_h,out_w) (not divided by 255, as in the reference)                           */
+int umt_resample_pinhole(const float* images, const float* xfs, int n, int h, int w, int out_h,
+                         int out_w, float* out, void* stream);
+
+/* ---- A3: _image_backbone, lib/models/umetrack_model.py:127-129, model_utils.py:107-138 ----
+ * images dev f32 (n,96,96) -> features dev f32 (n,72,6,6)                                          */
+int umt_backbone_forward(umt_model* m, const float* images, int n, int precision, float* features,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- A4-A7: _forward_feature_extractor after the backbone, umetrack_model.py:130-168,
+ * feature_extractor.py:61-141.  sample_range dev int64 (bs,2).  out dev f32 (bs,72,6,6)            */
+int umt_fuse_views(umt_model* m, const float* features, const float* intrinsics,
+                   const float* extrinsics, const int64_t* sample_range, int n, int bs, float* fused,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- A8: SimpleConvRNN.forward_temporal_features, lib/models/temporal.py:93-139 ----
+ * cam0_extrinsics dev f32 (bs,4,4) = extrinsics[sample_range[:,0]] (umetrack_model.py:93-97);
+ * memory_idx dev int64 (bs), use_memory dev uint8/bool (bs).  The caller must have reserved
+ * max(memory_idx)+1 rows.  out dev f32 (bs,72,6,6); updates the handle's state.                     */
+int umt_temporal_step(umt_model* m, const float* fused, const float* cam0_extrinsics,
+                      const int64_t* memory_idx, const uint8_t* use_memory, int bs, float* out,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- A9-A12: skeleton encoder + PoseRegressor.regress_poses + _recover_wrist_xfs_in_world,
+ * skeleton_encoder.py:43-53, regressor.py:163-186, umetrack_model.py:77-90,198-219,234-240 ----
+ * skel_axes/skel_rest dev f32 (n_skel,22,3), n_skel in {1, bs} (ignored for the scale head);
+ * outputs dev f32: joint_angles (bs,22), wrist_xfs (bs,4,4) in world, sigmas (bs,21),
+ * skel_scales (bs) (scale head only, else may be NULL), raw (bs,62|63) optional (may be NULL)      */
+int umt_regress_decode(umt_model* m, int head, const float* temporal, const float* skel_axes,
+                       const float* skel_rest, int n_skel, const float* cam0_extrinsics,
+                       const int64_t* hand_idx, int bs, float* joint_angles, float* wrist_xfs,
+                       float* sigmas, float* skel_scales, float* raw, void* workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* ---- whole model in one call: UmeTrackModel.regress_pose_use_skeleton / _pred_skel_scale,
+ * lib/models/umetrack_model.py:188-242.  Same buffers as the stage calls; intermediates stay in
+ * the library's channels-last layout inside `workspace`.                                            */
+int umt_model_forward(umt_model* m, int head, int precision, const float* images,
+                      const float* intrinsics, const float* extrinsics, const int64_t* sample_range,
+                      const int64_t* memory_idx, const uint8_t* use_memory, const int64_t* hand_idx,
+                      int n, int bs, const float* skel_axes, const float* skel_rest, int n_skel,
+                      float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- A14: skin_landmarks, lib/common/hand_skinning.py:189-209 (+ the right-hand mirror of
+ * landmarks_from_hand_pose, lib/tracker/perspective_crop.py:40-51 when mirror_right != 0) ----
+ * joint_angles dev f32 (b,22); wrist dev f32 (b,4,4); hand model arrays dev with n_model in {1,b}:
+ * axes,rest f32 (n_model,22,3); lm_rest f32 (n_model,21,3); lm_w f32 (n_model,21,3);
+ * lm_idx int32 (n_model,21,3); hand_idx dev int64 (b) or NULL; wrist_t_scale multiplies the wrist
+ * translation (1000 for the m->mm step of tracker.py:258); out dev f32 (b,21,3)                     */
+int umt_fk_landmarks(const float* joint_angles, const float* wrist, const float* axes,
+                     const float* rest, const float* lm_rest, const float* lm_w,
+                     const int32_t* lm_idx, int n_model, const int64_t* hand_idx, int mirror_right,
+                     float wrist_t_scale, int b, float* out, void* stream);
+
+/* ---- A15: _compute_metrics + the sums behind aggregate_metrics, load_eval.py:26-89,
+ * metric_utils.py:18-84.  gt/pred dev f32 (n_rec,2,T,21,3), valid dev uint8 (n_rec,2,T).
+ * partials dev float64[UMT_METRIC_WORDS]: sum_err, n_err, sum_acc, n_acc, sum_gt_acc, n_valid,
+ * n_total, then 101 PCK counts (errors <= linspace(0,50,101)[i]).  Written, not accumulated;
+ * deterministic (fixed-order two-stage reduction in `workspace`).                                   */
+#define UMT_METRIC_WORDS 108
+int64_t umt_metric_workspace_bytes(int n_rec, int t);
+int umt_metric_partials(const float* gt, const float* pred, const uint8_t* valid, int n_rec, int t,
+                        double* partials, void* workspace, int64_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMETRACK_HIP_H */

@@ -1,0 +1,269 @@
+"""GPU parity: HIP path (through the C ABI) vs the CPU oracle and the reference goldens.
+
+Tolerances (north star: fp32 keypoints within 0.01 mm = 1e-5 m per joint):
+  * wrist translation / landmarks: 1e-5 m  (0.01 mm)
+  * joint angles: 2e-5 rad (0.01 mm at a 0.2 m lever would be 5e-5 rad)
+  * intermediate feature maps: 2e-4 relative to the tensor's max magnitude
+"""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from oracle import fk as ofk
+from oracle import geometry as og
+from oracle import metrics as omx
+from oracle import model as om
+from umetrack_amd import _native as nat
+from umetrack_amd import arch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def _frame(step, device="cuda"):
+    from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
+    img = torch.from_numpy(step["images_u8"].astype(np.float32) / np.float32(255.0))
+    fd = InputFrameData(img.to(device), torch.from_numpy(step["intrinsics"]).to(device),
+                        torch.from_numpy(step["extrinsics"]).to(device))
+    desc = InputFrameDesc(torch.from_numpy(step["sample_range"]).to(device),
+                          torch.from_numpy(step["memory_idx"]).to(device),
+                          torch.from_numpy(step["use_memory"]).to(device),
+                          torch.from_numpy(step["hand_idx"]).to(device))
+    skel = None
+    if str(step["head"]) == "k":
+        skel = InputSkeletonData(torch.from_numpy(step["skel_axes"]).to(device),
+                                 torch.from_numpy(step["skel_rest"]).to(device))
+    return fd, desc, skel
+
+
+@pytest.fixture(scope="module")
+def gpu_model(golden_sequence):
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    _, seed = golden_sequence
+    return model_from_state_dict(arch.make_synthetic_state(seed)).to("cuda")
+
+
+def test_native_library_is_loaded():
+    nat.lib()
+    maps = open("/proc/self/maps").read()
+    assert "libumetrack_hip.so" in maps
+
+
+def test_model_sequence_matches_reference_goldens(golden_sequence, gpu_model):
+    """The reference's own outputs for a 6-step sequence on one model instance (memory on/off,
+    ragged views, growing memory, both heads)."""
+    steps, _ = golden_sequence
+    gpu_model.reset_memory()
+    for st in steps:
+        name = str(st["name"])
+        fd, desc, skel = _frame(st)
+        out = gpu_model.regress_pose_use_skeleton(fd, desc, skel) if skel is not None \
+            else gpu_model.regress_pose_pred_skel_scale(fd, desc)
+        ja, wx = out.joint_angles.cpu().numpy(), out.wrist_xfs.cpu().numpy()
+        assert np.abs(ja - st["joint_angles"]).max() < 2e-5, name
+        assert np.abs(wx[:, :3, 3] - st["wrist_xfs"][:, :3, 3]).max() < 1e-5, name          # metres
+        assert np.abs(wx[:, :3, :3] - st["wrist_xfs"][:, :3, :3]).max() < 2e-5, name
+        np.testing.assert_allclose(out.landmark_uncertainty_sigmas.cpu().numpy(), st["sigmas"], rtol=2e-4, atol=1e-6)
+        if "skel_scales" in st:
+            np.testing.assert_allclose(out.skel_scales.cpu().numpy(), st["skel_scales"], rtol=1e-4)
+        mem, prev = gpu_model.memory_state()
+        assert mem.shape[0] == st["memory"].shape[0], name
+        assert _rel(mem.cpu().numpy(), st["memory"]) < 2e-4, name
+        np.testing.assert_allclose(prev.cpu().numpy(), st["prev_ext"], atol=1e-7)
+
+
+def test_stage_entry_points_match_goldens(golden_sequence, gpu_model):
+    """Each C-ABI stage on its own, in the reference's tensor layouts."""
+    from umetrack_amd.lib.models.umetrack_model import InputSkeletonData
+    steps, _ = golden_sequence
+    gpu_model.reset_memory()
+    for st in steps:
+        name = str(st["name"])
+        fd, desc, skel = _frame(st)
+        feats = gpu_model.backbone(fd.left_images)
+        assert _rel(feats.cpu().numpy(), st["per_view"]) < 2e-4, name
+        fused = gpu_model.fuse_views(torch.from_numpy(st["per_view"]), fd.intrinsics, fd.extrinsics_xf, desc.sample_range)
+        assert _rel(fused.cpu().numpy(), st["fused"]) < 2e-4, name
+        cam0 = fd.extrinsics_xf[desc.sample_range[:, 0]]
+        temporal = gpu_model.temporal_step(torch.from_numpy(st["fused"]), cam0, desc.memory_idx, desc.use_memory)
+        assert _rel(temporal.cpu().numpy(), st["temporal"]) < 2e-4, name
+        head = nat.HEAD_KNOWN_SKELETON if skel is not None else nat.HEAD_PREDICT_SCALE
+        out, raw = gpu_model.regress_decode(head, torch.from_numpy(st["temporal"]), cam0, desc.hand_idx, skel)
+        assert np.abs(raw.cpu().numpy() - st["raw"]).max() < 2e-5, name
+        assert np.abs(out.wrist_xfs.cpu().numpy() - st["wrist_xfs"]).max() < 1e-5, name
+
+
+def test_model_matches_oracle_on_fresh_random_batch():
+    """A larger seeded batch (64 hands, all 2-view, 3 steps with memory) against the fp32 oracle
+    and against the fp64 oracle ('truth')."""
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
+    state = arch.make_synthetic_state(77)
+    gm = model_from_state_dict(state).to("cuda")
+    o32, o64 = om.OracleModel(state, torch.float32), om.OracleModel(state, torch.float64)
+    rng = np.random.default_rng(5)
+    bs = 64
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    hm = load_generic_hand_model()
+    skel = InputSkeletonData(hm.joint_rotation_axes, hm.joint_rest_positions * 0.001)
+    for step in range(3):
+        img = torch.from_numpy(rng.integers(0, 256, size=(2 * bs, 96, 96)).astype(np.float32) / np.float32(255))
+        K = torch.zeros(2 * bs, 3, 3)
+        K[:, 0, 0] = K[:, 1, 1] = torch.from_numpy(rng.uniform(150, 400, 2 * bs).astype(np.float32))
+        K[:, 0, 2] = K[:, 1, 2] = 47.5
+        K[:, 2, 2] = 1
+        from scipy.spatial.transform import Rotation
+        E = np.tile(np.eye(4, dtype=np.float32), (2 * bs, 1, 1))
+        E[:, :3, :3] = Rotation.from_rotvec(rng.normal(size=(2 * bs, 3)) * 0.5).as_matrix()
+        E[:, :3, 3] = rng.normal(size=(2 * bs, 3)) * 0.2
+        fd = InputFrameData(img, K, torch.from_numpy(E))
+        desc = InputFrameDesc(torch.arange(bs)[:, None] * 2 + torch.tensor([0, 2]), torch.arange(bs),
+                              torch.full((bs,), step > 0), torch.arange(bs) % 2)
+        got = gm.regress_pose_use_skeleton(fd, desc, skel)
+        with torch.no_grad():
+            r32 = o32.regress_pose_use_skeleton(fd, desc, skel)
+            r64 = o64.regress_pose_use_skeleton(fd, desc, skel)
+        t_got = got.wrist_xfs.cpu().numpy()[:, :3, 3]
+        e_oracle = np.abs(t_got - r32["wrist_xfs"].numpy()[:, :3, 3]).max()
+        e_truth = np.abs(t_got - r64["wrist_xfs"].numpy()[:, :3, 3]).max()
+        ref_truth = np.abs(r32["wrist_xfs"].numpy()[:, :3, 3] - r64["wrist_xfs"].numpy()[:, :3, 3]).max()
+        assert e_oracle < 1e-5, (step, e_oracle)                    # 0.01 mm
+        assert e_truth < max(1e-5, 3 * ref_truth), (step, e_truth, ref_truth)
+        assert np.abs(got.joint_angles.cpu().numpy() - r32["joint_angles"].numpy()).max() < 2e-5
+
+
+def test_fk_matches_oracle(hand_model_np):
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.common.hand_skinning import skin_landmarks
+    hm = load_generic_hand_model()
+    rng = np.random.default_rng(9)
+    lim = hand_model_np["joint_limits"]
+    from scipy.spatial.transform import Rotation
+    for lead in [(1,), (257,), (3, 5)]:
+        ja = rng.uniform(lim[:, 0], lim[:, 1], size=lead + (22,)).astype(np.float32)
+        ja[..., :3] *= rng.choice([1.0, 1e-3, 0.0], size=lead + (3,)).astype(np.float32)    # below the 1e-4 clamp too
+        W = np.tile(np.eye(4, dtype=np.float32), lead + (1, 1))
+        W[..., :3, :3] = Rotation.from_rotvec(rng.normal(size=(int(np.prod(lead)), 3))).as_matrix().reshape(lead + (3, 3))
+        W[..., :3, 3] = rng.normal(size=lead + (3,)) * 300
+        got = skin_landmarks(hm, torch.from_numpy(ja), torch.from_numpy(W)).cpu().numpy()
+        ref64 = ofk.skin_landmarks(hand_model_np, ja, W, np.float64)
+        ref32 = ofk.skin_landmarks(hand_model_np, ja, W, np.float32)
+        assert got.shape == lead + (21, 3)
+        assert np.abs(got - ref64).max() < 2e-3, np.abs(got - ref64).max()      # mm; fp32 rounding at ~1 m
+        assert np.abs(got - ref64).max() <= 3 * max(np.abs(ref32 - ref64).max(), 2e-4)
+    # rest pose reproduces the reference's landmark_rest_positions
+    rest = skin_landmarks(hm, torch.zeros(22), torch.eye(4)).cpu().numpy()
+    np.testing.assert_allclose(rest, hand_model_np["landmark_rest_positions"], atol=2e-5)
+    # per-sample models, right-hand mirror and m->mm scale
+    b = 6
+    ja = rng.uniform(lim[:, 0], lim[:, 1], size=(b, 22)).astype(np.float32)
+    W = np.tile(np.eye(4, dtype=np.float32), (b, 1, 1))
+    W[:, :3, 3] = rng.normal(size=(b, 3)) * 0.3
+    hidx = np.arange(b) % 2
+    scales = np.linspace(0.8, 1.2, b).astype(np.float32)
+    hmb = hm._replace(**{k: getattr(hm, k)[None].repeat(b, *([1] * getattr(hm, k).dim()))
+                         for k in ("joint_rotation_axes", "joint_rest_positions", "landmark_rest_positions",
+                                   "landmark_rest_bone_weights", "landmark_rest_bone_indices")})
+    hmb = hmb._replace(joint_rest_positions=hmb.joint_rest_positions * torch.from_numpy(scales)[:, None, None],
+                       landmark_rest_positions=hmb.landmark_rest_positions * torch.from_numpy(scales)[:, None, None])
+    got = skin_landmarks(hmb, torch.from_numpy(ja), torch.from_numpy(W), hand_idx=torch.from_numpy(hidx),
+                         mirror_right=True, wrist_translation_scale=1000.0).cpu().numpy()
+    for i in range(b):
+        mdl = dict(hand_model_np)
+        mdl["joint_rest_positions"] = hand_model_np["joint_rest_positions"] * scales[i]
+        mdl["landmark_rest_positions"] = hand_model_np["landmark_rest_positions"] * scales[i]
+        Wi = W[i].astype(np.float64).copy()
+        Wi[:3, 3] *= 1000.0
+        ref = ofk.landmarks_from_pose(mdl, ja[i], Wi, int(hidx[i]), np.float64)
+        assert np.abs(got[i] - ref).max() < 2e-3
+
+
+def _pack_case(g, i):
+    from umetrack_amd.lib.tracker import warp as w
+    W, H = (int(v) for v in g[f"{i}/src_wh"])
+    return (W, H, w.pack_fisheye(W, H, g[f"{i}/src_f"], g[f"{i}/src_c"], g[f"{i}/src_coeffs"], g[f"{i}/src_c2w"]),
+            w.pack_pinhole(g[f"{i}/dst_f"], g[f"{i}/dst_c"], g[f"{i}/dst_c2w"]))
+
+
+def test_warp_matches_oracle_and_reference_maps():
+    """Images warped on the GPU vs the oracle remap driven by the REFERENCE's maps."""
+    from umetrack_amd.lib.tracker import warp as w
+    g = load_npz("warp_maps.npz")
+    rng = np.random.default_rng(11)
+    n = int(g["n_cases"])
+    imgs, offs, pitches, sc, dc, srcs = [], [], [], [], [], []
+    pos = 0
+    for i in range(n):
+        W, H, s, d = _pack_case(g, i)
+        # smooth-ish image: low-res noise upsampled, plus fine noise
+        base = np.kron(rng.integers(0, 256, size=(H // 16 + 1, W // 16 + 1)), np.ones((16, 16)))[:H, :W]
+        img = np.clip(base + rng.integers(-30, 31, size=(H, W)), 0, 255).astype(np.uint8)
+        pitch = W + 7 * (i % 2)                       # odd pitches too (views inside a wider frame)
+        buf = np.zeros((H, pitch), np.uint8)
+        buf[:, :W] = img
+        pos += 3 * (i % 3)                            # unaligned starts
+        offs.append(pos)
+        pitches.append(pitch)
+        pos += buf.size
+        imgs.append((offs[-1], buf))
+        sc.append(s)
+        dc.append(d)
+        srcs.append(img)
+    flat = np.zeros(pos + 16, np.uint8)
+    for o, buf in imgs:
+        flat[o:o + buf.size] = buf.reshape(-1)
+    for mode, tol in ((w.MODE_CV2, 0.0), (w.MODE_FLOAT, 1e-6)):
+        got = w.warp_crops(torch.from_numpy(flat), offs, pitches, np.stack(sc), np.stack(dc), mode=mode).cpu().numpy()
+        for i in range(n):
+            mx, my = g[f"{i}/map_x"], g[f"{i}/map_y"]
+            if mode == w.MODE_CV2:
+                ref = og.remap_linear_u8(srcs[i], mx, my).astype(np.float32) / np.float32(255.0)
+                diff = np.abs(got[i] - ref) * 255
+                # device atan2/sqrt may differ from numpy by an ulp of the fp64 map, which can move a
+                # coordinate across a 1/32-px rounding boundary: allow a handful of 1-grey-level flips
+                assert (diff > 0.5).mean() < 2e-3, (i, (diff > 0.5).mean())
+                assert diff.max() <= 8.5, (i, diff.max())
+            else:
+                ref = og.remap_linear_f32(srcs[i], mx, my) / np.float32(255.0)
+                assert np.abs(got[i] - ref).max() < 2e-5, (i, np.abs(got[i] - ref).max())
+        assert (got[5] == 0).sum() >= int(g["5/n_behind"])     # depth-checked pixels are border (0)
+
+
+def test_resample_pinhole_matches_reference_golden():
+    from umetrack_amd.lib.batched_dataset.data_transform import resample_images_batched
+    g = load_npz("resample.npz")
+    got = resample_images_batched(torch.from_numpy(g["images"]), torch.from_numpy(g["xfs"])).cpu().numpy()
+    np.testing.assert_allclose(got, g["out"], rtol=0, atol=1e-3)          # grey levels 0..255
+    assert ((got == 0) == (g["out"] == 0)).mean() > 0.9995
+
+
+def test_metric_partials_match_reference_golden():
+    from umetrack_amd.lib.common import metric_utils as mu
+    g = load_npz("metrics.npz")
+    total = torch.zeros(nat.METRIC_WORDS, dtype=torch.float64, device="cuda")
+    recs = []
+    for r in range(int(g["n_rec"])):
+        gt, pred, valid = g[f"{r}/gt"], g[f"{r}/pred"], g[f"{r}/valid"]
+        gt32, pred32 = gt.astype(np.float32), pred.astype(np.float32)
+        if gt.shape[1] < 3:
+            continue
+        total += mu.metric_partials(torch.from_numpy(gt32), torch.from_numpy(pred32), torch.from_numpy(valid))
+        recs.append((gt32.astype(np.float64), pred32.astype(np.float64), valid))
+    agg = omx.aggregate(recs)
+    fin = mu.finalize_partials(total)
+    assert fin.n_valid == agg["n_valid"] and fin.n_total == agg["n_total"]
+    np.testing.assert_allclose(fin.mpjpe, agg["mpjpe"], rtol=1e-12)
+    np.testing.assert_allclose(fin.mpjpa, agg["mpjpa"], rtol=1e-12)
+    np.testing.assert_allclose(fin.gt_mpjpa, agg["gt_mpjpa"], rtol=1e-12)
+    np.testing.assert_array_equal(total.cpu().numpy()[7:].astype(np.int64), agg["pck_counts"])
+    np.testing.assert_allclose(fin.auc, agg["auc"], rtol=1e-12)
+    # and against the reference's float64 numbers (inputs rounded to float32 on the way in)
+    assert abs(fin.mpjpe - float(g["mpjpe"])) < 1e-4 and round(fin.mpjpe, 2) == round(float(g["mpjpe"]), 2)
+    assert round(fin.mpjpa, 2) == round(float(g["mpjpa"]), 2)

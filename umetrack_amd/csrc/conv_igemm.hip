@@ -1,0 +1,197 @@
+// Implicit-GEMM convolution on the CDNA4 fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+// Replaces every Conv2d(+BatchNorm2d)(+residual)(+ReLU) of the reference network
+// (lib/models/backbone_resnet.py:56-72, model_utils.py:134,141-163,195-208,
+// temporal.py:29-38).  GEMM view:  D[pixel][cout] = sum_k A[pixel][k] * B[k][cout],
+// k = (tap, cin).  Pixels are rows of the channels-last activation matrix, so an
+// A fragment is one 16-byte load of 4 consecutive input channels and a D row is
+// one contiguous 128-byte store of 32 output channels.
+//
+// MFMA operand map (32x32x2, wave64): lane l holds A[i = l&31][k = l>>5] and
+// B[k = l>>5][j = l&31]; D register r of lane l is row (r&3)+8*(r>>2)+4*(l>>5),
+// column l&31.  One ds_read_b128 per operand feeds four k-steps: lane (i,h) reads
+// channels c+4h..c+4h+3, so k-step t contracts channels {c+t, c+4+t}; the packed
+// weights use the same order.  fp32 MFMA is an exact k-ordered fmaf chain, so the
+// result differs from the reference's CPU convolution only by summation order.
+#include "umt_internal.h"
+
+namespace umt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* in;
+  const float* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  float* out;
+  int H, W, Ho, Wo;
+  int cin_s, cout_s, cout_w;
+  int stride, taps, relu;
+  int M;  // n * Ho * Wo output pixels
+};
+
+constexpr int KC = 32;        // input channels staged per step
+constexpr int LDA = KC + 4;   // padded A row (floats): 16 consecutive pixels hit 16 distinct 16-B slots
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int A_ROWS = BM / 32;  // float4 loads per thread per step
+  static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[BM * LDA + KC * BN];
+  float* sA = smem;
+  float* sB = smem + BM * LDA;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int pad = a.taps == 9 ? 1 : 0;
+  const int c8_total = a.cin_s >> 3;
+
+  // A staging: thread -> (pixel row ar + 32*r, channel quad ag)
+  const int ar = tid >> 3, ag = tid & 7;
+  int yi0[A_ROWS], xi0[A_ROWS];
+  int pixbase[A_ROWS];
+  bool rowok[A_ROWS];
+  const int hw_out = a.Ho * a.Wo;
+#pragma unroll
+  for (int r = 0; r < A_ROWS; ++r) {
+    const int m = m0 + ar + 32 * r;
+    rowok[r] = m < a.M;
+    const int mm = rowok[r] ? m : 0;
+    const int img = mm / hw_out;
+    const int rem = mm - img * hw_out;
+    const int yo = rem / a.Wo;
+    const int xo = rem - yo * a.Wo;
+    yi0[r] = yo * a.stride - pad;
+    xi0[r] = xo * a.stride - pad;
+    pixbase[r] = img * a.H * a.W;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int tap = 0; tap < a.taps; ++tap) {
+    const int ky = a.taps == 9 ? tap / 3 : 0;
+    const int kx = a.taps == 9 ? tap - 3 * ky : 0;
+    for (int c0 = 0; c0 < a.cin_s; c0 += KC) {
+      const int kc8 = min(KC / 8, c8_total - (c0 >> 3));
+      // ---- stage A: BM pixels x 32 channels of this tap ----
+#pragma unroll
+      for (int r = 0; r < A_ROWS; ++r) {
+        const int yi = yi0[r] + ky, xi = xi0[r] + kx;
+        const bool ok = rowok[r] && yi >= 0 && yi < a.H && xi >= 0 && xi < a.W &&
+                        (c0 + 4 * ag) < a.cin_s;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok)
+          v = *reinterpret_cast<const float4*>(
+              a.in + (size_t)(pixbase[r] + yi * a.W + xi) * a.cin_s + c0 + 4 * ag);
+        *reinterpret_cast<float4*>(sA + (ar + 32 * r) * LDA + 4 * ag) = v;
+      }
+      // ---- stage B: kc8 x 2 x BN float4 of packed weights ----
+      {
+        const float* wsrc = a.w + ((size_t)tap * c8_total + (c0 >> 3)) * 2 * a.cout_w * 4;
+        for (int idx = tid; idx < kc8 * 2 * BN; idx += 256) {
+          const int row = idx / BN;  // c8l*2 + h
+          const int j = idx - row * BN;
+          *reinterpret_cast<float4*>(sB + (size_t)idx * 4) =
+              *reinterpret_cast<const float4*>(wsrc + ((size_t)row * a.cout_w + n0 + j) * 4);
+        }
+      }
+      __syncthreads();
+      for (int c8l = 0; c8l < kc8; ++c8l) {
+        float4 av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          av[i] = *reinterpret_cast<const float4*>(sA + ((wm * TM + i) * 32 + li) * LDA + c8l * 8 + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bv[j] = *reinterpret_cast<const float4*>(sB + ((size_t)(c8l * 2 + lh) * BN + (wn * TN + j) * 32 + li) * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: conv bias -> BN scale/shift -> residual -> ReLU, 128-B row stores ----
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + (wn * TN + j) * 32 + li;
+    if (co >= a.cout_s) continue;
+    const float cb = a.bias[co], cs = a.scale[co], ch = a.shift[co];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = m0 + (wm * TM + i) * 32 + row;
+        if (m < a.M) {
+          const size_t o = (size_t)m * a.cout_s + co;
+          float v = (acc[i][j][r] + cb) * cs + ch;
+          if (a.residual) v += a.residual[o];
+          if (a.relu) v = fmaxf(v, 0.f);
+          a.out[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static void launch_cfg(const ConvArgs& a, hipStream_t stream) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
+  hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), 0, stream, a);
+}
+
+int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
+                float* out, hipStream_t stream) {
+  UMT_REQUIRE(L.taps == 1 || L.taps == 9, UMT_ERR_INVALID, "conv: taps must be 1 or 9, got %d", L.taps);
+  UMT_REQUIRE(L.stride == 1 || L.stride == 2, UMT_ERR_INVALID, "conv: stride %d", L.stride);
+  UMT_REQUIRE(L.cin_s % 8 == 0 && L.cout_s % 8 == 0 && L.cout_w % 32 == 0 && L.cout_s <= L.cout_w,
+              UMT_ERR_INVALID, "conv: channel strides %d/%d/%d", L.cin_s, L.cout_s, L.cout_w);
+  UMT_REQUIRE(n > 0 && h > 0 && w > 0, UMT_ERR_INVALID, "conv: empty input");
+  ConvArgs a;
+  a.in = in; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+  a.residual = residual; a.out = out;
+  a.H = h; a.W = w;
+  const int pad = L.taps == 9 ? 1 : 0, k = L.taps == 9 ? 3 : 1;
+  a.Ho = (h + 2 * pad - k) / L.stride + 1;
+  a.Wo = (w + 2 * pad - k) / L.stride + 1;
+  a.cin_s = L.cin_s; a.cout_s = L.cout_s; a.cout_w = L.cout_w;
+  a.stride = L.stride; a.taps = L.taps; a.relu = L.relu;
+  const int64_t M = (int64_t)n * a.Ho * a.Wo;
+  UMT_REQUIRE(M < (int64_t)1 << 31 && (int64_t)n * h * w < (int64_t)1 << 31, UMT_ERR_INVALID,
+              "conv: %lld output pixels exceed the 32-bit pixel index", (long long)M);
+  a.M = (int)M;
+  if (L.cout_w % 128 == 0) launch_cfg<2, 2, 2, 2>(a, stream);
+  else if (L.cout_w == 96) launch_cfg<4, 1, 1, 3>(a, stream);
+  else if (L.cout_w == 64) launch_cfg<2, 2, 2, 1>(a, stream);
+  else if (L.cout_w == 32) launch_cfg<4, 1, 1, 1>(a, stream);
+  else return set_error(UMT_ERR_INVALID, "conv: unsupported padded cout %d", L.cout_w);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace umt

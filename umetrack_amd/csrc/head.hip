@@ -1,0 +1,492 @@
+// Small kernels between the convolutions of the head: feature-transform layer (FTL),
+// view concatenation, temporal memory gather/scatter, skeleton encoder, global average
+// pool, pose decode (Procrustes) and layout converters for the C-ABI stage boundaries.
+// All of them move a few KB per hand; none is on the roofline-critical path.
+//
+// 4x4 algebra is evaluated in double precision from the float32 inputs and rounded once,
+// which lands within float32 rounding of the reference's float32 torch.inverse / matmul /
+// svd chains (lib/models/feature_extractor.py:61-87, temporal.py:51-78, model_utils.py:17-54,
+// umetrack_model.py:77-90).
+#include "umt_internal.h"
+
+namespace umt {
+
+static inline unsigned grid_for(int64_t total, int block) { return (unsigned)((total + block - 1) / block); }
+
+// ---------------------------------------------------------------- small device linear algebra
+__device__ inline void mat4_mul(const double* a, const double* b, double* c) {
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
+      c[i * 4 + j] = s;
+    }
+}
+
+// Gauss-Jordan with partial pivoting; a singular input yields inf/nan like torch.inverse would raise.
+__device__ inline void mat4_inv(const double* m, double* inv) {
+  double a[4][8];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      a[i][j] = m[i * 4 + j];
+      a[i][4 + j] = (i == j) ? 1.0 : 0.0;
+    }
+  for (int col = 0; col < 4; ++col) {
+    int piv = col;
+    double best = fabs(a[col][col]);
+    for (int r = col + 1; r < 4; ++r)
+      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+    if (piv != col)
+      for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+    const double d = 1.0 / a[col][col];
+    for (int j = 0; j < 8; ++j) a[col][j] *= d;
+    for (int r = 0; r < 4; ++r)
+      if (r != col) {
+        const double f = a[r][col];
+        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
+      }
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
+}
+
+__device__ inline void load_mat4(const float* src, double* dst) {
+  for (int i = 0; i < 16; ++i) dst[i] = (double)src[i];
+}
+
+// ---------------------------------------------------------------- layout converters
+__global__ void rows_to_nchw_kernel(const float* rows, int cs, int c0, int c, int64_t total, int hw, float* nchw) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int p = (int)(t % hw);
+  const int ch = (int)((t / hw) % c);
+  const int64_t b = t / ((int64_t)hw * c);
+  nchw[t] = rows[(b * hw + p) * cs + c0 + ch];
+}
+
+__global__ void nchw_to_rows_kernel(const float* nchw, int c, int64_t total, int hw, float* rows, int cs, int c0) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int ch = (int)(t % c);
+  const int p = (int)((t / c) % hw);
+  const int64_t b = t / ((int64_t)hw * c);
+  rows[(b * hw + p) * cs + c0 + ch] = nchw[(b * c + ch) * hw + p];
+}
+
+__global__ void zero_channels_kernel(float* rows, int cs, int c0, int c, int64_t total) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  rows[(t / c) * cs + c0 + (t % c)] = 0.f;
+}
+
+int launch_rows_to_nchw(const float* rows, int cs, int c0, int c, int n, int hw, float* nchw, hipStream_t s) {
+  const int64_t total = (int64_t)n * c * hw;
+  hipLaunchKernelGGL(rows_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, rows, cs, c0, c, total, hw, nchw);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_nchw_to_rows(const float* nchw, int c, int n, int hw, float* rows, int cs, int c0, hipStream_t s) {
+  const int64_t total = (int64_t)n * c * hw;
+  hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, nchw, c, total, hw, rows, cs, c0);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_zero_channels(float* rows, int cs, int c0, int c, int64_t nrows, hipStream_t s) {
+  if (c <= 0 || nrows <= 0) return 0;
+  const int64_t total = nrows * c;
+  hipLaunchKernelGGL(zero_channels_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, rows, cs, c0, c, total);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void gather_cam0_kernel(const float* ext, const int64_t* sr, int n, int bs, float* cam0) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * 16) return;
+  const int b = t >> 4;
+  int64_t r0 = sr[2 * b];
+  r0 = r0 < 0 ? 0 : (r0 >= n ? n - 1 : r0);   // an out-of-range index must not fault the GPU
+  cam0[t] = ext[r0 * 16 + (t & 15)];
+}
+
+int launch_gather_cam0(const float* extrinsics, const int64_t* sample_range, int n, int bs, float* cam0, hipStream_t s) {
+  hipLaunchKernelGGL(gather_cam0_kernel, dim3(grid_for((int64_t)bs * 16, 256)), dim3(256), 0, s, extrinsics, sample_range, n, bs, cam0);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- fusion transforms (A4, A5)
+// crop_xf[n][12]: rows of [R|t] taking view features to the canonical space (2-view samples).
+// sample_xf[bs][12]: canonical -> cam0 (= S of the sample's first crop).  sample_views[bs]: 1 or 2
+// (0 marks a malformed range; its outputs become NaN instead of reading out of bounds).
+__global__ void fusion_xforms_kernel(const float* K, const float* E, const int64_t* sr, int n, int bs,
+                                     float* crop_xf, float* sample_xf, int32_t* sample_views) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bs) return;
+  const int64_t r0 = sr[2 * b], r1 = sr[2 * b + 1];
+  const int nv = (int)(r1 - r0);
+  const bool okr = r0 >= 0 && r1 <= n && (nv == 1 || nv == 2);
+  sample_views[b] = okr ? nv : 0;
+  if (!okr) {
+    for (int i = 0; i < 12; ++i) sample_xf[b * 12 + i] = __builtin_nanf("");
+    return;
+  }
+  const double s0 = (double)(K[r0 * 9] / 200.0f);   // model_utils.py:188-190, float32 division
+  {
+    float* o = sample_xf + b * 12;
+    for (int i = 0; i < 12; ++i) o[i] = 0.f;
+    o[0] = 1.f; o[5] = 1.f; o[10] = (float)s0;
+  }
+  if (nv == 2) {
+    double e0[16], s0inv_e0[16];
+    load_mat4(E + r0 * 16, e0);
+    for (int i = 0; i < 16; ++i) s0inv_e0[i] = e0[i];
+    for (int j = 0; j < 4; ++j) s0inv_e0[8 + j] = e0[8 + j] / s0;   // inverse(S0) @ E0 scales row 2
+    for (int v = 0; v < 2; ++v) {
+      double ev[16], evi[16], tw[16], tc[16];
+      load_mat4(E + (r0 + v) * 16, ev);
+      mat4_inv(ev, evi);
+      const double sv = (double)(K[(r0 + v) * 9] / 200.0f);
+      for (int i = 0; i < 16; ++i) tw[i] = evi[i];
+      for (int i = 0; i < 4; ++i) tw[i * 4 + 2] = evi[i * 4 + 2] * sv;     // inverse(E_v) @ S_v scales column 2
+      mat4_mul(s0inv_e0, tw, tc);
+      float* o = crop_xf + (r0 + v) * 12;
+      for (int i = 0; i < 12; ++i) o[i] = (float)tc[i];
+    }
+  }
+}
+
+int launch_fusion_xforms(const float* intrinsics, const float* extrinsics, const int64_t* sample_range,
+                         int n, int bs, float* crop_xf, float* sample_xf, int32_t* sample_views, hipStream_t s) {
+  hipLaunchKernelGGL(fusion_xforms_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, intrinsics, extrinsics,
+                     sample_range, n, bs, crop_xf, sample_xf, sample_views);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// FTL on channels-last rows: the reference reshapes (C,6,6) to (3, C/3*36), so channel c,
+// c+C/3, c+2C/3 of one pixel form one 3-D point (model_utils.py:89-99).
+__device__ inline void ftl_point(const float* xf, float x, float y, float z, float& ox, float& oy, float& oz) {
+  ox = xf[0] * x + xf[1] * y + xf[2] * z + xf[3];
+  oy = xf[4] * x + xf[5] * y + xf[6] * z + xf[7];
+  oz = xf[8] * x + xf[9] * y + xf[10] * z + xf[11];
+}
+
+// cat_rows [bs*36][144]: channels v*72.. of sample b = FTL(to_canon[r0+v]) of crop r0+v; zeros for 1-view samples
+__global__ void ftl_concat_kernel(const float* feat, const float* crop_xf, const int64_t* sr,
+                                  const int32_t* views, int bs, float* cat) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)bs * 36 * 2 * 24) return;
+  const int c = (int)(t % 24);
+  const int v = (int)((t / 24) % 2);
+  const int p = (int)((t / 48) % 36);
+  const int b = (int)(t / (48 * 36));
+  float* o = cat + ((size_t)b * 36 + p) * 144 + v * 72;
+  if (views[b] != 2) {
+    const float fill = views[b] == 1 ? 0.f : __builtin_nanf("");
+    o[c] = fill; o[c + 24] = fill; o[c + 48] = fill;
+    return;
+  }
+  const int64_t crop = sr[2 * b] + v;
+  const float* f = feat + ((size_t)crop * 36 + p) * 72;
+  float x, y, z;
+  ftl_point(crop_xf + crop * 12, f[c], f[c + 24], f[c + 48], x, y, z);
+  o[c] = x; o[c + 24] = y; o[c + 48] = z;
+}
+
+int launch_ftl_concat(const float* feat_rows, const float* crop_xf, const int64_t* sample_range,
+                      const int32_t* sample_views, int n, int bs, float* cat_rows, hipStream_t s) {
+  (void)n;
+  hipLaunchKernelGGL(ftl_concat_kernel, dim3(grid_for((int64_t)bs * 36 * 48, 256)), dim3(256), 0, s, feat_rows,
+                     crop_xf, sample_range, sample_views, bs, cat_rows);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[b] = FTL(S0) of the fused conv output (2 views) or FTL(S) of the crop's own features (1 view)
+__global__ void ftl_select_kernel(const float* conv, const float* feat, const float* sample_xf, const int64_t* sr,
+                                  const int32_t* views, int bs, float* out, int out_cs, int out_c0) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)bs * 36 * 24) return;
+  const int c = (int)(t % 24);
+  const int p = (int)((t / 24) % 36);
+  const int b = (int)(t / (24 * 36));
+  const float* f = views[b] == 2 ? conv + ((size_t)b * 36 + p) * 72
+                                 : feat + ((size_t)(views[b] == 1 ? sr[2 * b] : 0) * 36 + p) * 72;
+  float x, y, z;
+  ftl_point(sample_xf + b * 12, f[c], f[c + 24], f[c + 48], x, y, z);
+  float* o = out + ((size_t)b * 36 + p) * out_cs + out_c0;
+  o[c] = x; o[c + 24] = y; o[c + 48] = z;
+}
+
+int launch_ftl_select(const float* conv_rows, const float* feat_rows, const float* sample_xf,
+                      const int64_t* sample_range, const int32_t* sample_views, int n, int bs,
+                      float* out_rows, int out_cs, int out_c0, hipStream_t s) {
+  (void)n;
+  hipLaunchKernelGGL(ftl_select_kernel, dim3(grid_for((int64_t)bs * 36 * 24, 256)), dim3(256), 0, s, conv_rows,
+                     feat_rows, sample_xf, sample_range, sample_views, bs, out_rows, out_cs, out_c0);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- temporal memory (A8)
+// One thread per sample: relative transform cur_E . inverse(prev_E[idx]) (temporal.py:65-69),
+// then prev_E[idx] = cur_E (temporal.py:77).  rel_xf[b][12]; rows without memory get NaN-free zeros.
+__global__ void temporal_xforms_kernel(float* prev_ext, int mem_rows, const float* cam0, const int64_t* midx,
+                                       const uint8_t* use, int bs, float* rel_xf, int32_t* row_of) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bs) return;
+  const int64_t idx = midx[b];
+  const bool okr = idx >= 0 && idx < mem_rows;
+  row_of[b] = okr ? (int32_t)idx : -1;
+  float* o = rel_xf + b * 12;
+  for (int i = 0; i < 12; ++i) o[i] = 0.f;
+  if (!okr) return;
+  if (use[b]) {
+    double pe[16], pinv[16], ce[16], rel[16];
+    load_mat4(prev_ext + idx * 16, pe);
+    load_mat4(cam0 + b * 16, ce);
+    mat4_inv(pe, pinv);
+    mat4_mul(ce, pinv, rel);
+    for (int i = 0; i < 12; ++i) o[i] = (float)rel[i];
+  }
+  for (int i = 0; i < 16; ++i) prev_ext[idx * 16 + i] = cam0[b * 16 + i];
+}
+
+// tin_rows[b*36+p][0..17] = use ? FTL(rel, mem[idx]) : 0   (temporal.py:59-74, 83-85); mem is (rows,18,6,6)
+__global__ void temporal_gather_kernel(const float* mem, const float* rel_xf, const int32_t* row_of,
+                                       const uint8_t* use, int bs, float* tin, int tin_cs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * 36 * 6) return;
+  const int c = t % 6;
+  const int p = (t / 6) % 36;
+  const int b = t / (6 * 36);
+  float x = 0.f, y = 0.f, z = 0.f;
+  const int row = row_of[b];
+  if (row >= 0 && use[b]) {
+    const float* m = mem + (size_t)row * 18 * 36;
+    ftl_point(rel_xf + b * 12, m[c * 36 + p], m[(c + 6) * 36 + p], m[(c + 12) * 36 + p], x, y, z);
+  }
+  float* o = tin + ((size_t)b * 36 + p) * tin_cs;
+  o[c] = x; o[c + 6] = y; o[c + 12] = z;
+}
+
+int launch_temporal_gather(float* mem, float* prev_ext, int mem_rows, const float* cam0_ext,
+                           const int64_t* memory_idx, const uint8_t* use_memory, int bs, float* tin_rows,
+                           int tin_cs, float* rel_xf, int32_t* row_of, hipStream_t s) {
+  hipLaunchKernelGGL(temporal_xforms_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, prev_ext, mem_rows, cam0_ext,
+                     memory_idx, use_memory, bs, rel_xf, row_of);
+  hipLaunchKernelGGL(temporal_gather_kernel, dim3(grid_for((int64_t)bs * 36 * 6, 256)), dim3(256), 0, s, mem,
+                     rel_xf, row_of, use_memory, bs, tin_rows, tin_cs);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// channels 0..17 of the temporal output overwrite the memory row, 18..89 go on (temporal.py:88-89,134)
+__global__ void temporal_split_kernel(const float* tout, int tout_cs, float* mem, const int32_t* row_of, int bs,
+                                      float* out, int out_cs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * 36 * 90) return;
+  const int c = t % 90;
+  const int p = (t / 90) % 36;
+  const int b = t / (90 * 36);
+  const float v = tout[((size_t)b * 36 + p) * tout_cs + c];
+  if (c < 18) {
+    const int row = row_of[b];
+    if (row >= 0) mem[(size_t)row * 18 * 36 + c * 36 + p] = v;
+  } else {
+    out[((size_t)b * 36 + p) * out_cs + (c - 18)] = v;
+  }
+}
+
+int launch_temporal_split(const float* tout_rows, int tout_cs, float* mem, const int32_t* row_of, int bs,
+                          float* out_rows, int out_cs, hipStream_t s) {
+  hipLaunchKernelGGL(temporal_split_kernel, dim3(grid_for((int64_t)bs * 36 * 90, 256)), dim3(256), 0, s, tout_rows,
+                     tout_cs, mem, row_of, bs, out_rows, out_cs);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- skeleton encoder (A9)
+// Linear(132,144) on cat(axes, rest) per joint -> view (4,6,6) -> BN(4) -> ReLU (skeleton_encoder.py:36-53);
+// a single profile is broadcast to every sample (umetrack_model.py:202-207).
+__global__ void skeleton_kernel(SkelParams p, const float* axes, const float* rest, int n_skel, int bs,
+                                float* rows, int cs, int c0) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * 144) return;
+  const int o = t % 144;
+  const int b = t / 144;
+  const int sk = n_skel == 1 ? 0 : b;
+  const float* a = axes + (size_t)sk * 66;
+  const float* r = rest + (size_t)sk * 66;
+  const float* w = p.w + (size_t)o * 132;
+  float s = 0.f;
+  for (int j = 0; j < 22; ++j) {
+    s = fmaf(w[j * 6 + 0], a[j * 3 + 0], s);
+    s = fmaf(w[j * 6 + 1], a[j * 3 + 1], s);
+    s = fmaf(w[j * 6 + 2], a[j * 3 + 2], s);
+    s = fmaf(w[j * 6 + 3], r[j * 3 + 0], s);
+    s = fmaf(w[j * 6 + 4], r[j * 3 + 1], s);
+    s = fmaf(w[j * 6 + 5], r[j * 3 + 2], s);
+  }
+  const int c = o / 36, px = o % 36;
+  const float v = fmaxf((s + p.bias[o]) * p.scale[c] + p.shift[c], 0.f);
+  rows[((size_t)b * 36 + px) * cs + c0 + c] = v;
+}
+
+int launch_skeleton(const SkelParams& p, const float* axes, const float* rest, int n_skel, int bs, float* rows,
+                    int cs, int c0, hipStream_t s) {
+  hipLaunchKernelGGL(skeleton_kernel, dim3(grid_for((int64_t)bs * 144, 256)), dim3(256), 0, s, p, axes, rest, n_skel,
+                     bs, rows, cs, c0);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- global average pool (A10 tail)
+__global__ void avgpool_kernel(const float* rows, int cs, int c, int bs, float* raw) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * c) return;
+  const int ch = t % c;
+  const int b = t / c;
+  const float* r = rows + (size_t)b * 36 * cs + ch;
+  float s = 0.f;
+  for (int p = 0; p < 36; ++p) s += r[(size_t)p * cs];
+  raw[t] = s / 36.f;
+}
+
+int launch_avgpool(const float* rows, int cs, int c, int bs, float* raw, hipStream_t s) {
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((int64_t)bs * c, 256)), dim3(256), 0, s, rows, cs, c, bs, raw);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- pose decode (A11, A12)
+// 3x3 SVD by one-sided Jacobi (Hestenes): rotates column pairs of A = H and of V until the
+// columns of A are orthogonal; then A = U*diag(s).  Only R = V*diag(1,1,det(V U^T))*U^T is
+// used, which is unique whenever the reference's result is (SURVEY.md section 7 "hard parts").
+__device__ inline void kabsch_rotation(const double* H, double* R) {
+  double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  for (int i = 0; i < 9; ++i) A[i] = H[i];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    double off = 0;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double al = 0, be = 0, ga = 0;
+        for (int i = 0; i < 3; ++i) {
+          al += A[i * 3 + p] * A[i * 3 + p];
+          be += A[i * 3 + q] * A[i * 3 + q];
+          ga += A[i * 3 + p] * A[i * 3 + q];
+        }
+        if (fabs(ga) <= 1e-300 || fabs(ga) <= 1e-17 * sqrt(al * be)) continue;
+        off = fmax(off, fabs(ga) / sqrt(al * be));
+        const double zeta = (be - al) / (2.0 * ga);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int i = 0; i < 3; ++i) {
+          const double ap = A[i * 3 + p], aq = A[i * 3 + q];
+          A[i * 3 + p] = c * ap - s * aq;
+          A[i * 3 + q] = s * ap + c * aq;
+          const double vp = V[i * 3 + p], vq = V[i * 3 + q];
+          V[i * 3 + p] = c * vp - s * vq;
+          V[i * 3 + q] = s * vp + c * vq;
+        }
+      }
+    if (off < 1e-15) break;
+  }
+  double sv[3], U[9];
+  int kmin = 0;
+  for (int j = 0; j < 3; ++j) {
+    sv[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    if (sv[j] < sv[kmin]) kmin = j;
+  }
+  const int ka = (kmin + 1) % 3, kb = (kmin + 2) % 3;
+  for (int j = 0; j < 3; ++j)
+    if (j != kmin) {
+      const double inv = sv[j] > 0 ? 1.0 / sv[j] : 0.0;
+      for (int i = 0; i < 3; ++i) U[i * 3 + j] = A[i * 3 + j] * inv;
+    }
+  const double smax = fmax(sv[ka], sv[kb]);
+  if (sv[kmin] > 1e-12 * smax) {
+    for (int i = 0; i < 3; ++i) U[i * 3 + kmin] = A[i * 3 + kmin] / sv[kmin];
+  } else {  // rank-2 H: complete U with the cross product (any sign gives the same R after the det fix)
+    U[0 * 3 + kmin] = U[1 * 3 + ka] * U[2 * 3 + kb] - U[2 * 3 + ka] * U[1 * 3 + kb];
+    U[1 * 3 + kmin] = U[2 * 3 + ka] * U[0 * 3 + kb] - U[0 * 3 + ka] * U[2 * 3 + kb];
+    U[2 * 3 + kmin] = U[0 * 3 + ka] * U[1 * 3 + kb] - U[1 * 3 + ka] * U[0 * 3 + kb];
+  }
+  auto det3 = [](const double* m) {
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  };
+  const double d = det3(V) * det3(U);   // det(V U^T), +-1 up to rounding
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = 0;
+      for (int k = 0; k < 3; ++k) s += V[i * 3 + k] * (k == kmin ? d : 1.0) * U[j * 3 + k];
+      R[i * 3 + j] = s;
+    }
+}
+
+__global__ void decode_kernel(const float* raw, int nraw, int predict_scale, const float* cam0, const int64_t* hand_idx,
+                              int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bs) return;
+  const float* r = raw + (size_t)b * nraw;
+  // regressor.py:76-85
+  for (int i = 0; i < 20; ++i) joint_angles[b * 22 + i] = r[i];
+  joint_angles[b * 22 + 20] = 0.f;
+  joint_angles[b * 22 + 21] = 0.f;
+  // regressor.py:19-47, 88-104: seven source points, float32 like the reference's tensor
+  const double raw_src[7][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, -1, 0}, {-1, 0, -1}, {0, -1, -1}};
+  double src[7][3], dst[7][3], ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+  for (int i = 0; i < 7; ++i) {
+    const double nrm = sqrt(raw_src[i][0] * raw_src[i][0] + raw_src[i][1] * raw_src[i][1] + raw_src[i][2] * raw_src[i][2]);
+    for (int k = 0; k < 3; ++k) {
+      src[i][k] = nrm > 0 ? (double)(float)(raw_src[i][k] / nrm * 0.1) : 0.0;
+      dst[i][k] = (double)r[20 + i * 3 + k];
+      ms[k] += src[i][k];
+      md[k] += dst[i][k];
+    }
+  }
+  for (int k = 0; k < 3; ++k) { ms[k] /= 7.0; md[k] /= 7.0; }
+  double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // model_utils.py:36-39: from_centered^T @ to_centered
+  for (int i = 0; i < 7; ++i)
+    for (int a = 0; a < 3; ++a)
+      for (int c = 0; c < 3; ++c) H[a * 3 + c] += (src[i][a] - ms[a]) * (dst[i][c] - md[c]);
+  double R[9];
+  kabsch_rotation(H, R);
+  double wc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) wc[i * 4 + j] = R[i * 3 + j];
+    wc[i * 4 + 3] = md[i] - (R[i * 3 + 0] * ms[0] + R[i * 3 + 1] * ms[1] + R[i * 3 + 2] * ms[2]);
+  }
+  // umetrack_model.py:77-90: inverse(cam0 extrinsics) @ wrist, mirror x for right hands
+  double e[16], ei[16], ww[16];
+  load_mat4(cam0 + b * 16, e);
+  mat4_inv(e, ei);
+  mat4_mul(ei, wc, ww);
+  const bool right = hand_idx[b] == 1;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) wrist_xfs[b * 16 + i * 4 + j] = (float)((right && j == 0) ? -ww[i * 4 + j] : ww[i * 4 + j]);
+  int o = 41;
+  if (predict_scale) {   // regressor.py:107-114
+    skel_scales[b] = expf(r[41]);
+    o = 42;
+  }
+  for (int i = 0; i < 21; ++i) {   // regressor.py:117-121: clamp(softplus(x), 1e-5), torch threshold 20
+    const float x = r[o + i];
+    const float sp = x > 20.f ? x : (float)log1p(exp((double)x));
+    sigmas[b * 21 + i] = fmaxf(sp, 1e-5f);
+  }
+}
+
+int launch_decode(const float* raw, int nraw, int predict_scale, const float* cam0_ext, const int64_t* hand_idx,
+                  int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales, hipStream_t s) {
+  UMT_REQUIRE(nraw == (predict_scale ? 63 : 62), UMT_ERR_INVALID, "decode: nraw = %d", nraw);
+  UMT_REQUIRE(!predict_scale || skel_scales, UMT_ERR_INVALID, "decode: scale head needs a skel_scales buffer");
+  hipLaunchKernelGGL(decode_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, raw, nraw, predict_scale, cam0_ext,
+                     hand_idx, bs, joint_angles, wrist_xfs, sigmas, skel_scales);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace umt

@@ -1,0 +1,709 @@
+// Model handle, strict parameter table, weight packing and the stage / whole-model entry points.
+// Mirrors what lib/models/model_loader.py:53-88 builds and what UmeTrackModel
+// (lib/models/umetrack_model.py:100-242) runs, on channels-last rows and the kernels in
+// conv_igemm.hip / stem.hip / head.hip.
+#include "umt_internal.h"
+
+#include <string.h>
+#include <math.h>
+
+namespace umt {
+
+static thread_local char g_err[1024] = "";
+
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+struct ParamSpec {
+  std::string key;
+  int ndim;
+  int64_t shape[4];
+  bool is_int64;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    return n;
+  }
+};
+
+struct BlockLayers {
+  ConvLayer conv1, conv2, down;
+  bool has_down = false;
+};
+
+struct PackJob {   // one conv to pack at finalize
+  ConvLayer* dst;
+  std::string w, b, bn;   // keys ("" = absent)
+};
+
+constexpr float BN_EPS = 1e-5f;
+constexpr int N_STAGE_BLOCKS[4] = {2, 3, 5, 2};
+constexpr int ACT_FLOATS = 48 * 48 * 32;   // largest activation per crop (stage 1)
+constexpr int DS_FLOATS = 24 * 24 * 64;    // largest downsample branch per crop
+
+}  // namespace umt
+
+using namespace umt;
+
+struct umt_model {
+  std::vector<ParamSpec> spec;
+  std::map<std::string, int> index;
+  std::vector<std::vector<float>> values;   // host copies (int64 counters are validated, not kept)
+  std::vector<char> seen;
+  bool finalized = false;
+  int device = -1;
+  float* slab = nullptr;   // all packed weights
+  // network
+  StemParams stem{};
+  std::vector<BlockLayers> blocks;   // 12 backbone blocks
+  std::vector<int> block_hw;         // input H (=W) of each block
+  ConvLayer proj, fuse1, fuse2, fuse3, temp[3];
+  SkelParams skel{};
+  BlockLayers reg_blocks[2][2];
+  ConvLayer reg_out[2];
+  // temporal state (temporal.py:41-42)
+  float* mem = nullptr;        // (rows,18,6,6)
+  float* prev_ext = nullptr;   // (rows,4,4)
+  int mem_rows = 0;
+  int mem_cap = 0;
+};
+
+namespace umt {
+
+static void add_param(umt_model* m, const std::string& key, std::initializer_list<int64_t> shape, bool is_int = false) {
+  ParamSpec p;
+  p.key = key;
+  p.ndim = (int)shape.size();
+  int i = 0;
+  for (int64_t s : shape) p.shape[i++] = s;
+  for (; i < 4; ++i) p.shape[i] = 1;
+  p.is_int64 = is_int;
+  m->index[key] = (int)m->spec.size();
+  m->spec.push_back(p);
+}
+
+static void add_bn(umt_model* m, const std::string& p, int c) {
+  add_param(m, p + ".weight", {c});
+  add_param(m, p + ".bias", {c});
+  add_param(m, p + ".running_mean", {c});
+  add_param(m, p + ".running_var", {c});
+  add_param(m, p + ".num_batches_tracked", {}, true);
+}
+
+static void add_conv(umt_model* m, const std::string& p, int cout, int cin, int k, bool bias) {
+  add_param(m, p + ".weight", {cout, cin, k, k});
+  if (bias) add_param(m, p + ".bias", {cout});
+}
+
+static void add_block(umt_model* m, const std::string& p, int cin, int cout, bool down) {
+  add_conv(m, p + ".conv1", cout, cin, 3, false);
+  add_bn(m, p + ".bn1", cout);
+  add_conv(m, p + ".conv2", cout, cout, 3, false);
+  add_bn(m, p + ".bn2", cout);
+  if (down) {
+    add_conv(m, p + ".downsample.0", cout, cin, 1, false);
+    add_bn(m, p + ".downsample.1", cout);
+  }
+}
+
+// the reference's state_dict, in its order
+static void build_spec(umt_model* m) {
+  const std::string bb = "_feature_extractor._image_backbone";
+  add_conv(m, bb + ".0._layers.0.0", 32, 1, 3, true);
+  add_bn(m, bb + ".0._layers.0.1", 32);
+  const int cin[4] = {32, 32, 64, 128}, cout[4] = {32, 64, 128, 256}, stride[4] = {1, 2, 2, 2};
+  for (int s = 0; s < 4; ++s)
+    for (int b = 0; b < N_STAGE_BLOCKS[s]; ++b) {
+      const bool first = b == 0;
+      add_block(m, bb + ".0._layers." + std::to_string(s + 1) + "." + std::to_string(b), first ? cin[s] : cout[s],
+                cout[s], first && (stride[s] != 1 || cin[s] != cout[s]));
+    }
+  add_conv(m, bb + ".1", 72, 256, 1, true);
+  const std::string fu = "_feature_extractor._multi_view_fusion";
+  add_conv(m, fu + ".0", 108, 144, 1, true);
+  add_bn(m, fu + ".1", 108);
+  add_conv(m, fu + ".3", 72, 108, 1, true);
+  add_bn(m, fu + ".4", 72);
+  add_conv(m, fu + ".6", 72, 72, 1, true);
+  for (int i = 0; i < 3; ++i) add_conv(m, "_temporal._temporal_module." + std::to_string(2 * i), 90, 90, 1, true);
+  add_param(m, "_skeleton_enc._layers.0.weight", {144, 132});
+  add_param(m, "_skeleton_enc._layers.0.bias", {144});
+  add_bn(m, "_skeleton_enc._layers.2", 4);
+  const char* heads[2] = {"_regressor_k", "_regressor_u"};
+  const int hc[2] = {76, 72}, ho[2] = {62, 63};
+  for (int h = 0; h < 2; ++h) {
+    const std::string p = std::string(heads[h]) + "._pose_regression_layers";
+    for (int b = 0; b < 2; ++b) add_block(m, p + "." + std::to_string(b), hc[h], hc[h], false);
+    add_conv(m, p + ".2", ho[h], hc[h], 1, true);
+  }
+  m->values.resize(m->spec.size());
+  m->seen.assign(m->spec.size(), 0);
+}
+
+static const std::vector<float>& val(const umt_model* m, const std::string& key) { return m->values[m->index.at(key)]; }
+
+// Appends one packed conv (weights + bias/scale/shift) to `host`; pointers are stored as offsets first.
+struct Packed {
+  ConvLayer* layer;
+  size_t w_off, b_off, s_off, h_off;
+};
+
+static void pack_conv(const umt_model* m, std::vector<float>& host, std::vector<Packed>& packed, ConvLayer* L,
+                      const std::string& wkey, const std::string& bkey, const std::string& bn, int stride, int relu) {
+  const ParamSpec& ps = m->spec[m->index.at(wkey)];
+  const int cout = (int)ps.shape[0], cin = (int)ps.shape[1], k = (int)ps.shape[2];
+  L->taps = k * k;
+  L->cin = cin;
+  L->cout = cout;
+  L->cin_s = round_up(cin, 8);
+  L->cout_s = round_up(cout, 8);
+  L->cout_w = round_up(cout, 32);
+  L->stride = stride;
+  L->relu = relu;
+  const std::vector<float>& w = val(m, wkey);
+  const int c8 = L->cin_s / 8;
+  Packed p;
+  p.layer = L;
+  p.w_off = host.size();
+  host.resize(host.size() + (size_t)L->taps * c8 * 2 * L->cout_w * 4, 0.f);
+  float* dst = host.data() + p.w_off;
+  // packed[tap][c8][h][co][q] = W[co][ci = 8*c8 + 4*h + q][ky][kx]   (see conv_igemm.hip)
+  for (int tap = 0; tap < L->taps; ++tap)
+    for (int g = 0; g < c8; ++g)
+      for (int h = 0; h < 2; ++h)
+        for (int co = 0; co < cout; ++co)
+          for (int q = 0; q < 4; ++q) {
+            const int ci = 8 * g + 4 * h + q;
+            if (ci < cin)
+              dst[((((size_t)tap * c8 + g) * 2 + h) * L->cout_w + co) * 4 + q] = w[((size_t)co * cin + ci) * L->taps + tap];
+          }
+  p.b_off = host.size();
+  host.resize(host.size() + L->cout_w, 0.f);
+  p.s_off = host.size();
+  host.resize(host.size() + L->cout_w, 1.f);
+  p.h_off = host.size();
+  host.resize(host.size() + L->cout_w, 0.f);
+  if (!bkey.empty()) {
+    const std::vector<float>& b = val(m, bkey);
+    for (int c = 0; c < cout; ++c) host[p.b_off + c] = b[c];
+  }
+  if (!bn.empty()) {
+    // eval-mode BN as torch evaluates it on CPU: alpha = gamma / sqrt(var + eps), beta = bias - mean * alpha
+    const std::vector<float>&g = val(m, bn + ".weight"), &be = val(m, bn + ".bias"), &mu = val(m, bn + ".running_mean"),
+                            &var = val(m, bn + ".running_var");
+    for (int c = 0; c < cout; ++c) {
+      const float alpha = g[c] / sqrtf(var[c] + BN_EPS);
+      host[p.s_off + c] = alpha;
+      host[p.h_off + c] = be[c] - mu[c] * alpha;
+    }
+  }
+  packed.push_back(p);
+}
+
+static void pack_block(const umt_model* m, std::vector<float>& host, std::vector<Packed>& packed, BlockLayers* B,
+                       const std::string& p, int stride, bool down) {
+  pack_conv(m, host, packed, &B->conv1, p + ".conv1.weight", "", p + ".bn1", stride, 1);
+  pack_conv(m, host, packed, &B->conv2, p + ".conv2.weight", "", p + ".bn2", 1, 1);   // ReLU after the residual add
+  B->has_down = down;
+  if (down) pack_conv(m, host, packed, &B->down, p + ".downsample.0.weight", "", p + ".downsample.1", stride, 0);
+}
+
+// ---- workspace carving ----
+struct Carver {
+  char* base;
+  int64_t off = 0, cap;
+  Carver(void* p, int64_t c) : base((char*)p), cap(c) {}
+  template <typename T>
+  T* take(int64_t count) {
+    T* r = (T*)(base + off);
+    off += round_up64(count * (int64_t)sizeof(T), 256);
+    return r;
+  }
+};
+
+struct BackboneWs {
+  float *a, *b, *c, *d, *feat;
+};
+static int64_t carve_backbone(Carver& cv, int n, BackboneWs* w) {
+  w->a = cv.take<float>((int64_t)n * ACT_FLOATS);
+  w->b = cv.take<float>((int64_t)n * ACT_FLOATS);
+  w->c = cv.take<float>((int64_t)n * ACT_FLOATS);
+  w->d = cv.take<float>((int64_t)n * DS_FLOATS);
+  w->feat = cv.take<float>((int64_t)n * 36 * 72);
+  return cv.off;
+}
+
+struct HeadWs {
+  float *feat_in;   // used by the stage entry points only
+  float *crop_xf, *sample_xf, *cam0, *rel_xf;
+  int32_t *views, *row_of;
+  float *cat, *f1, *f2, *f3, *tin, *t1, *t2, *rin, *r1, *r2, *r3, *rout, *raw;
+};
+static int64_t carve_head(Carver& cv, int n, int bs, HeadWs* w) {
+  const int64_t px = (int64_t)bs * 36;
+  w->feat_in = cv.take<float>((int64_t)n * 36 * 72);
+  w->crop_xf = cv.take<float>((int64_t)n * 12);
+  w->sample_xf = cv.take<float>((int64_t)bs * 12);
+  w->cam0 = cv.take<float>((int64_t)bs * 16);
+  w->rel_xf = cv.take<float>((int64_t)bs * 12);
+  w->views = cv.take<int32_t>(bs);
+  w->row_of = cv.take<int32_t>(bs);
+  w->cat = cv.take<float>(px * 144);
+  w->f1 = cv.take<float>(px * 112);
+  w->f2 = cv.take<float>(px * 72);
+  w->f3 = cv.take<float>(px * 72);
+  w->tin = cv.take<float>(px * 96);
+  w->t1 = cv.take<float>(px * 96);
+  w->t2 = cv.take<float>(px * 96);
+  w->rin = cv.take<float>(px * 80);
+  w->r1 = cv.take<float>(px * 80);
+  w->r2 = cv.take<float>(px * 80);
+  w->r3 = cv.take<float>(px * 80);
+  w->rout = cv.take<float>(px * 64);
+  w->raw = cv.take<float>((int64_t)bs * 64);
+  return cv.off;
+}
+
+static int check_ready(const umt_model* m) {
+  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
+  UMT_REQUIRE(m->finalized, UMT_ERR_STATE, "model is not finalized (call umt_model_finalize first)");
+  int dev = -1;
+  UMT_CHECK_HIP(hipGetDevice(&dev));
+  UMT_REQUIRE(dev == m->device, UMT_ERR_STATE, "current device %d differs from the model's device %d", dev, m->device);
+  return 0;
+}
+
+// ---- stages on channels-last rows ----
+static int backbone_rows(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
+  UMT_TRY(launch_stem(m->stem, images, n, w.a, s));
+  float *x = w.a, *t = w.b, *y = w.c;
+  for (size_t i = 0; i < m->blocks.size(); ++i) {
+    const BlockLayers& B = m->blocks[i];
+    const int hw = m->block_hw[i];
+    UMT_TRY(launch_conv(B.conv1, x, n, hw, hw, nullptr, t, s));
+    const float* res = x;
+    if (B.has_down) {
+      UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, w.d, s));
+      res = w.d;
+    }
+    const int hw2 = hw / B.conv1.stride;
+    UMT_TRY(launch_conv(B.conv2, t, n, hw2, hw2, res, y, s));
+    float* old = x;
+    x = y;
+    y = old;
+  }
+  UMT_TRY(launch_conv(m->proj, x, n, 6, 6, nullptr, w.feat, s));
+  return 0;
+}
+
+// feat rows [n*36][72] -> fused features written into tin channels 18..89
+static int fuse_rows(umt_model* m, const float* feat, const float* K, const float* E, const int64_t* sr, int n, int bs,
+                     const HeadWs& w, hipStream_t s) {
+  UMT_TRY(launch_fusion_xforms(K, E, sr, n, bs, w.crop_xf, w.sample_xf, w.views, s));
+  UMT_TRY(launch_ftl_concat(feat, w.crop_xf, sr, w.views, n, bs, w.cat, s));
+  UMT_TRY(launch_conv(m->fuse1, w.cat, bs, 6, 6, nullptr, w.f1, s));
+  UMT_TRY(launch_conv(m->fuse2, w.f1, bs, 6, 6, nullptr, w.f2, s));
+  UMT_TRY(launch_conv(m->fuse3, w.f2, bs, 6, 6, nullptr, w.f3, s));
+  UMT_CHECK_HIP(hipMemsetAsync(w.tin, 0, (size_t)bs * 36 * 96 * sizeof(float), s));
+  UMT_TRY(launch_ftl_select(w.f3, feat, w.sample_xf, sr, w.views, n, bs, w.tin, 96, 18, s));
+  return 0;
+}
+
+// tin (channels 18..89 set) -> temporal output in out_rows[.., 0..71] with stride out_cs; updates the state
+static int temporal_rows(umt_model* m, const float* cam0, const int64_t* midx, const uint8_t* use, int bs,
+                         const HeadWs& w, float* out_rows, int out_cs, hipStream_t s) {
+  UMT_REQUIRE(m->mem_rows > 0, UMT_ERR_STATE, "temporal: no memory rows reserved (umt_model_reserve_memory)");
+  UMT_TRY(launch_temporal_gather(m->mem, m->prev_ext, m->mem_rows, cam0, midx, use, bs, w.tin, 96, w.rel_xf, w.row_of, s));
+  UMT_TRY(launch_conv(m->temp[0], w.tin, bs, 6, 6, nullptr, w.t1, s));
+  UMT_TRY(launch_conv(m->temp[1], w.t1, bs, 6, 6, nullptr, w.t2, s));
+  UMT_TRY(launch_conv(m->temp[2], w.t2, bs, 6, 6, nullptr, w.t1, s));
+  UMT_TRY(launch_temporal_split(w.t1, 96, m->mem, w.row_of, bs, out_rows, out_cs, s));
+  return 0;
+}
+
+// rin (channels 0..71 set; head k: 72..75 filled here) -> decoded outputs
+static int regress_rows(umt_model* m, int head, const float* skel_axes, const float* skel_rest, int n_skel,
+                        const float* cam0, const int64_t* hand_idx, int bs, const HeadWs& w, float* joint_angles,
+                        float* wrist_xfs, float* sigmas, float* skel_scales, float* raw_out, hipStream_t s) {
+  const int cs = head == UMT_HEAD_KNOWN_SKELETON ? 80 : 72;
+  const int nraw = head == UMT_HEAD_KNOWN_SKELETON ? 62 : 63;
+  if (head == UMT_HEAD_KNOWN_SKELETON) {
+    UMT_REQUIRE(skel_axes && skel_rest, UMT_ERR_INVALID, "known-skeleton head needs skeleton data");
+    UMT_REQUIRE(n_skel == 1 || n_skel == bs, UMT_ERR_INVALID, "n_skel must be 1 or bs (%d), got %d", bs, n_skel);
+    UMT_TRY(launch_skeleton(m->skel, skel_axes, skel_rest, n_skel, bs, w.rin, cs, 72, s));
+  }
+  const BlockLayers* B = m->reg_blocks[head];
+  UMT_TRY(launch_conv(B[0].conv1, w.rin, bs, 6, 6, nullptr, w.r1, s));
+  UMT_TRY(launch_conv(B[0].conv2, w.r1, bs, 6, 6, w.rin, w.r2, s));
+  UMT_TRY(launch_conv(B[1].conv1, w.r2, bs, 6, 6, nullptr, w.r1, s));
+  UMT_TRY(launch_conv(B[1].conv2, w.r1, bs, 6, 6, w.r2, w.r3, s));
+  UMT_TRY(launch_conv(m->reg_out[head], w.r3, bs, 6, 6, nullptr, w.rout, s));
+  UMT_TRY(launch_avgpool(w.rout, 64, nraw, bs, w.raw, s));
+  if (raw_out) UMT_CHECK_HIP(hipMemcpyAsync(raw_out, w.raw, (size_t)bs * nraw * sizeof(float), hipMemcpyDeviceToDevice, s));
+  UMT_TRY(launch_decode(w.raw, nraw, head == UMT_HEAD_PREDICT_SCALE, cam0, hand_idx, bs, joint_angles, wrist_xfs, sigmas,
+                        skel_scales, s));
+  return 0;
+}
+
+}  // namespace umt
+
+// =====================================================================================  C ABI
+extern "C" const char* umt_last_error(void) { return g_err; }
+extern "C" int umt_abi_version(void) { return 1; }
+
+extern "C" int umt_model_create(umt_model** out) {
+  UMT_REQUIRE(out, UMT_ERR_INVALID, "umt_model_create: null out pointer");
+  umt_model* m = new umt_model();
+  build_spec(m);
+  *out = m;
+  return 0;
+}
+
+extern "C" int umt_model_destroy(umt_model* m) {
+  if (!m) return 0;
+  if (m->finalized) {
+    int prev = -1;
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(m->device) == hipSuccess) {
+      if (m->slab) (void)hipFree(m->slab);
+      if (m->mem) (void)hipFree(m->mem);
+      if (m->prev_ext) (void)hipFree(m->prev_ext);
+      (void)hipSetDevice(prev);
+    }
+  }
+  delete m;
+  return 0;
+}
+
+extern "C" int umt_model_param_count(const umt_model* m, int* count) {
+  UMT_REQUIRE(m && count, UMT_ERR_INVALID, "null argument");
+  *count = (int)m->spec.size();
+  return 0;
+}
+
+extern "C" int umt_model_param_info(const umt_model* m, int index, const char** key, int* ndim, int64_t shape[4],
+                                    int* is_int64) {
+  UMT_REQUIRE(m && key && ndim && shape && is_int64, UMT_ERR_INVALID, "null argument");
+  UMT_REQUIRE(index >= 0 && index < (int)m->spec.size(), UMT_ERR_INVALID, "parameter index %d out of range", index);
+  const ParamSpec& p = m->spec[index];
+  *key = p.key.c_str();
+  *ndim = p.ndim;
+  for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  *is_int64 = p.is_int64 ? 1 : 0;
+  return 0;
+}
+
+extern "C" int umt_model_set_param(umt_model* m, const char* key, const void* host_data, int ndim, const int64_t* shape,
+                                   int is_int64) {
+  UMT_REQUIRE(m && key && host_data, UMT_ERR_INVALID, "null argument");
+  UMT_REQUIRE(!m->finalized, UMT_ERR_STATE, "model already finalized");
+  auto it = m->index.find(key);
+  UMT_REQUIRE(it != m->index.end(), UMT_ERR_KEY, "Unexpected key in state_dict: \"%s\"", key);
+  const ParamSpec& p = m->spec[it->second];
+  UMT_REQUIRE(ndim == p.ndim && (is_int64 != 0) == p.is_int64, UMT_ERR_KEY,
+              "size mismatch for %s: got %d dims (int64=%d), expected %d dims (int64=%d)", key, ndim, is_int64, p.ndim,
+              (int)p.is_int64);
+  for (int i = 0; i < ndim; ++i)
+    UMT_REQUIRE(shape && shape[i] == p.shape[i], UMT_ERR_KEY, "size mismatch for %s: dim %d is %lld, expected %lld", key,
+                i, (long long)(shape ? shape[i] : -1), (long long)p.shape[i]);
+  if (!p.is_int64) {
+    const float* src = (const float*)host_data;
+    m->values[it->second].assign(src, src + p.numel());
+  }
+  m->seen[it->second] = 1;
+  return 0;
+}
+
+extern "C" int umt_model_finalize(umt_model* m, int device) {
+  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
+  UMT_REQUIRE(!m->finalized, UMT_ERR_STATE, "model already finalized");
+  for (size_t i = 0; i < m->spec.size(); ++i)
+    UMT_REQUIRE(m->seen[i], UMT_ERR_KEY, "Missing key in state_dict: \"%s\"", m->spec[i].key.c_str());
+  int ndev = 0;
+  UMT_CHECK_HIP(hipGetDeviceCount(&ndev));
+  UMT_REQUIRE(device >= 0 && device < ndev, UMT_ERR_INVALID, "device %d not available (%d devices)", device, ndev);
+  hipDeviceProp_t prop;
+  UMT_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  UMT_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, UMT_ERR_UNSUPPORTED,
+              "libumetrack_hip is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
+  UMT_CHECK_HIP(hipSetDevice(device));
+
+  std::vector<float> host;
+  std::vector<Packed> packed;
+  host.reserve(6u << 20);
+  // stem: weights as [tap][32]
+  const std::string bb = "_feature_extractor._image_backbone";
+  size_t stem_off[4];
+  {
+    const std::vector<float>&w = val(m, bb + ".0._layers.0.0.weight"), &b = val(m, bb + ".0._layers.0.0.bias");
+    const std::string bn = bb + ".0._layers.0.1";
+    stem_off[0] = host.size();
+    host.resize(host.size() + 9 * 32);
+    for (int tap = 0; tap < 9; ++tap)
+      for (int c = 0; c < 32; ++c) host[stem_off[0] + tap * 32 + c] = w[c * 9 + tap];
+    stem_off[1] = host.size();
+    host.insert(host.end(), b.begin(), b.end());
+    stem_off[2] = host.size();
+    host.resize(host.size() + 32);
+    stem_off[3] = host.size();
+    host.resize(host.size() + 32);
+    const std::vector<float>&g = val(m, bn + ".weight"), &be = val(m, bn + ".bias"), &mu = val(m, bn + ".running_mean"),
+                            &var = val(m, bn + ".running_var");
+    for (int c = 0; c < 32; ++c) {
+      const float alpha = g[c] / sqrtf(var[c] + BN_EPS);
+      host[stem_off[2] + c] = alpha;
+      host[stem_off[3] + c] = be[c] - mu[c] * alpha;
+    }
+  }
+  int nblocks = 0;
+  for (int s = 0; s < 4; ++s) nblocks += N_STAGE_BLOCKS[s];
+  m->blocks.resize(nblocks);
+  m->block_hw.resize(nblocks);
+  {
+    const int stride[4] = {1, 2, 2, 2};
+    int hw = 48, bi = 0;
+    for (int s = 0; s < 4; ++s)
+      for (int b = 0; b < N_STAGE_BLOCKS[s]; ++b, ++bi) {
+        const bool first = b == 0;
+        const std::string p = bb + ".0._layers." + std::to_string(s + 1) + "." + std::to_string(b);
+        m->block_hw[bi] = hw;
+        pack_block(m, host, packed, &m->blocks[bi], p, first ? stride[s] : 1, first && s > 0);
+        if (first) hw /= stride[s];
+      }
+  }
+  pack_conv(m, host, packed, &m->proj, bb + ".1.weight", bb + ".1.bias", "", 1, 0);
+  const std::string fu = "_feature_extractor._multi_view_fusion";
+  pack_conv(m, host, packed, &m->fuse1, fu + ".0.weight", fu + ".0.bias", fu + ".1", 1, 1);
+  pack_conv(m, host, packed, &m->fuse2, fu + ".3.weight", fu + ".3.bias", fu + ".4", 1, 1);
+  pack_conv(m, host, packed, &m->fuse3, fu + ".6.weight", fu + ".6.bias", "", 1, 0);
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = "_temporal._temporal_module." + std::to_string(2 * i);
+    pack_conv(m, host, packed, &m->temp[i], p + ".weight", p + ".bias", "", 1, i < 2 ? 1 : 0);
+  }
+  const char* heads[2] = {"_regressor_k", "_regressor_u"};
+  for (int h = 0; h < 2; ++h) {
+    const std::string p = std::string(heads[h]) + "._pose_regression_layers";
+    for (int b = 0; b < 2; ++b) pack_block(m, host, packed, &m->reg_blocks[h][b], p + "." + std::to_string(b), 1, false);
+    pack_conv(m, host, packed, &m->reg_out[h], p + ".2.weight", p + ".2.bias", "", 1, 0);
+  }
+  // skeleton encoder
+  size_t sk_off[4];
+  {
+    const std::vector<float>&w = val(m, "_skeleton_enc._layers.0.weight"), &b = val(m, "_skeleton_enc._layers.0.bias");
+    sk_off[0] = host.size();
+    host.insert(host.end(), w.begin(), w.end());
+    sk_off[1] = host.size();
+    host.insert(host.end(), b.begin(), b.end());
+    const std::string bn = "_skeleton_enc._layers.2";
+    const std::vector<float>&g = val(m, bn + ".weight"), &be = val(m, bn + ".bias"), &mu = val(m, bn + ".running_mean"),
+                            &var = val(m, bn + ".running_var");
+    sk_off[2] = host.size();
+    host.resize(host.size() + 4);
+    sk_off[3] = host.size();
+    host.resize(host.size() + 4);
+    for (int c = 0; c < 4; ++c) {
+      const float alpha = g[c] / sqrtf(var[c] + BN_EPS);
+      host[sk_off[2] + c] = alpha;
+      host[sk_off[3] + c] = be[c] - mu[c] * alpha;
+    }
+  }
+  // every packed array starts 16-B aligned: all sizes above are multiples of 4 floats
+  for (const Packed& p : packed)
+    UMT_REQUIRE(p.w_off % 4 == 0 && p.b_off % 4 == 0, UMT_ERR_STATE, "internal: packed offsets not 16-B aligned");
+  UMT_CHECK_HIP(hipMalloc((void**)&m->slab, host.size() * sizeof(float)));
+  UMT_CHECK_HIP(hipMemcpy(m->slab, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+  for (const Packed& p : packed) {
+    p.layer->w = m->slab + p.w_off;
+    p.layer->bias = m->slab + p.b_off;
+    p.layer->scale = m->slab + p.s_off;
+    p.layer->shift = m->slab + p.h_off;
+  }
+  m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3]};
+  m->skel = SkelParams{m->slab + sk_off[0], m->slab + sk_off[1], m->slab + sk_off[2], m->slab + sk_off[3]};
+  m->device = device;
+  m->finalized = true;
+  std::vector<std::vector<float>>().swap(m->values);
+  return 0;
+}
+
+extern "C" int umt_model_reserve_memory(umt_model* m, int rows, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(rows >= 0, UMT_ERR_INVALID, "reserve_memory: rows = %d", rows);
+  if (rows <= m->mem_rows) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (rows > m->mem_cap) {
+    const int cap = rows > 2 * m->mem_cap ? rows : 2 * m->mem_cap;
+    float *nm = nullptr, *np = nullptr;
+    UMT_CHECK_HIP(hipMalloc((void**)&nm, (size_t)cap * 18 * 36 * sizeof(float)));
+    UMT_CHECK_HIP(hipMalloc((void**)&np, (size_t)cap * 16 * sizeof(float)));
+    if (m->mem_rows > 0) {
+      UMT_CHECK_HIP(hipMemcpyAsync(nm, m->mem, (size_t)m->mem_rows * 18 * 36 * sizeof(float), hipMemcpyDeviceToDevice, s));
+      UMT_CHECK_HIP(hipMemcpyAsync(np, m->prev_ext, (size_t)m->mem_rows * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    UMT_CHECK_HIP(hipStreamSynchronize(s));   // old buffers are freed below; growth is rare (per new hand slot)
+    if (m->mem) UMT_CHECK_HIP(hipFree(m->mem));
+    if (m->prev_ext) UMT_CHECK_HIP(hipFree(m->prev_ext));
+    m->mem = nm;
+    m->prev_ext = np;
+    m->mem_cap = cap;
+  }
+  // new rows start at zero (temporal.py:106-120)
+  UMT_CHECK_HIP(hipMemsetAsync(m->mem + (size_t)m->mem_rows * 18 * 36, 0, (size_t)(rows - m->mem_rows) * 18 * 36 * sizeof(float), s));
+  UMT_CHECK_HIP(hipMemsetAsync(m->prev_ext + (size_t)m->mem_rows * 16, 0, (size_t)(rows - m->mem_rows) * 16 * sizeof(float), s));
+  m->mem_rows = rows;
+  return 0;
+}
+
+extern "C" int umt_model_memory_rows(const umt_model* m, int* rows) {
+  UMT_REQUIRE(m && rows, UMT_ERR_INVALID, "null argument");
+  *rows = m->mem_rows;
+  return 0;
+}
+
+extern "C" int umt_model_clear_memory(umt_model* m) {
+  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
+  m->mem_rows = 0;   // capacity is kept; rows are re-zeroed when reserved again
+  return 0;
+}
+
+extern "C" int umt_model_read_memory(const umt_model* m, float* mem_dev, float* prev_ext_dev, void* stream) {
+  UMT_TRY(check_ready(m));
+  if (m->mem_rows == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (mem_dev)
+    UMT_CHECK_HIP(hipMemcpyAsync(mem_dev, m->mem, (size_t)m->mem_rows * 18 * 36 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (prev_ext_dev)
+    UMT_CHECK_HIP(hipMemcpyAsync(prev_ext_dev, m->prev_ext, (size_t)m->mem_rows * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+extern "C" int64_t umt_backbone_workspace_bytes(int n_crops) {
+  Carver cv(nullptr, 0);
+  BackboneWs w;
+  return carve_backbone(cv, n_crops > 0 ? n_crops : 1, &w);
+}
+
+extern "C" int64_t umt_head_workspace_bytes(int n_crops, int n_samples) {
+  Carver cv(nullptr, 0);
+  HeadWs w;
+  return carve_head(cv, n_crops > 0 ? n_crops : 1, n_samples > 0 ? n_samples : 1, &w);
+}
+
+extern "C" int64_t umt_forward_workspace_bytes(int n_crops, int n_samples) {
+  return umt_backbone_workspace_bytes(n_crops) + umt_head_workspace_bytes(n_crops, n_samples);
+}
+
+static int check_ws(const char* what, void* ws, int64_t have, int64_t need) {
+  UMT_REQUIRE(ws, UMT_ERR_WORKSPACE, "%s: null workspace", what);
+  UMT_REQUIRE(((uintptr_t)ws & 255) == 0, UMT_ERR_WORKSPACE, "%s: workspace must be 256-byte aligned", what);
+  UMT_REQUIRE(have >= need, UMT_ERR_WORKSPACE, "%s: workspace has %lld bytes, needs %lld", what, (long long)have,
+              (long long)need);
+  return 0;
+}
+
+extern "C" int umt_backbone_forward(umt_model* m, const float* images, int n, int precision, float* features,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(precision == UMT_PREC_FP32, UMT_ERR_UNSUPPORTED, "backbone: only UMT_PREC_FP32 is implemented");
+  UMT_REQUIRE(n > 0 && images && features, UMT_ERR_INVALID, "backbone: n=%d or null pointer", n);
+  UMT_TRY(check_ws("backbone", workspace, workspace_bytes, umt_backbone_workspace_bytes(n)));
+  Carver cv(workspace, workspace_bytes);
+  BackboneWs w;
+  carve_backbone(cv, n, &w);
+  hipStream_t s = (hipStream_t)stream;
+  UMT_TRY(backbone_rows(m, images, n, w, s));
+  UMT_TRY(launch_rows_to_nchw(w.feat, 72, 0, 72, n, 36, features, s));
+  return 0;
+}
+
+extern "C" int umt_fuse_views(umt_model* m, const float* features, const float* intrinsics, const float* extrinsics,
+                              const int64_t* sample_range, int n, int bs, float* fused, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(n > 0 && bs > 0 && features && intrinsics && extrinsics && sample_range && fused, UMT_ERR_INVALID,
+              "fuse_views: bad argument");
+  UMT_TRY(check_ws("fuse_views", workspace, workspace_bytes, umt_head_workspace_bytes(n, bs)));
+  Carver cv(workspace, workspace_bytes);
+  HeadWs w;
+  carve_head(cv, n, bs, &w);
+  hipStream_t s = (hipStream_t)stream;
+  UMT_TRY(launch_nchw_to_rows(features, 72, n, 36, w.feat_in, 72, 0, s));
+  UMT_TRY(fuse_rows(m, w.feat_in, intrinsics, extrinsics, sample_range, n, bs, w, s));
+  UMT_TRY(launch_rows_to_nchw(w.tin, 96, 18, 72, bs, 36, fused, s));
+  return 0;
+}
+
+extern "C" int umt_temporal_step(umt_model* m, const float* fused, const float* cam0_extrinsics,
+                                 const int64_t* memory_idx, const uint8_t* use_memory, int bs, float* out,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(bs > 0 && fused && cam0_extrinsics && memory_idx && use_memory && out, UMT_ERR_INVALID,
+              "temporal_step: bad argument");
+  UMT_TRY(check_ws("temporal_step", workspace, workspace_bytes, umt_head_workspace_bytes(1, bs)));
+  Carver cv(workspace, workspace_bytes);
+  HeadWs w;
+  carve_head(cv, 1, bs, &w);
+  hipStream_t s = (hipStream_t)stream;
+  UMT_CHECK_HIP(hipMemsetAsync(w.tin, 0, (size_t)bs * 36 * 96 * sizeof(float), s));
+  UMT_TRY(launch_nchw_to_rows(fused, 72, bs, 36, w.tin, 96, 18, s));
+  UMT_TRY(temporal_rows(m, cam0_extrinsics, memory_idx, use_memory, bs, w, w.f2, 72, s));
+  UMT_TRY(launch_rows_to_nchw(w.f2, 72, 0, 72, bs, 36, out, s));
+  return 0;
+}
+
+extern "C" int umt_regress_decode(umt_model* m, int head, const float* temporal, const float* skel_axes,
+                                  const float* skel_rest, int n_skel, const float* cam0_extrinsics,
+                                  const int64_t* hand_idx, int bs, float* joint_angles, float* wrist_xfs, float* sigmas,
+                                  float* skel_scales, float* raw, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(head == UMT_HEAD_KNOWN_SKELETON || head == UMT_HEAD_PREDICT_SCALE, UMT_ERR_INVALID, "head = %d", head);
+  UMT_REQUIRE(bs > 0 && temporal && cam0_extrinsics && hand_idx && joint_angles && wrist_xfs && sigmas, UMT_ERR_INVALID,
+              "regress_decode: bad argument");
+  UMT_TRY(check_ws("regress_decode", workspace, workspace_bytes, umt_head_workspace_bytes(1, bs)));
+  Carver cv(workspace, workspace_bytes);
+  HeadWs w;
+  carve_head(cv, 1, bs, &w);
+  hipStream_t s = (hipStream_t)stream;
+  const int cs = head == UMT_HEAD_KNOWN_SKELETON ? 80 : 72;
+  UMT_CHECK_HIP(hipMemsetAsync(w.rin, 0, (size_t)bs * 36 * 80 * sizeof(float), s));
+  UMT_TRY(launch_nchw_to_rows(temporal, 72, bs, 36, w.rin, cs, 0, s));
+  UMT_TRY(regress_rows(m, head, skel_axes, skel_rest, n_skel, cam0_extrinsics, hand_idx, bs, w, joint_angles, wrist_xfs,
+                       sigmas, skel_scales, raw, s));
+  return 0;
+}
+
+extern "C" int umt_model_forward(umt_model* m, int head, int precision, const float* images, const float* intrinsics,
+                                 const float* extrinsics, const int64_t* sample_range, const int64_t* memory_idx,
+                                 const uint8_t* use_memory, const int64_t* hand_idx, int n, int bs,
+                                 const float* skel_axes, const float* skel_rest, int n_skel, float* joint_angles,
+                                 float* wrist_xfs, float* sigmas, float* skel_scales, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(precision == UMT_PREC_FP32, UMT_ERR_UNSUPPORTED, "forward: only UMT_PREC_FP32 is implemented");
+  UMT_REQUIRE(head == UMT_HEAD_KNOWN_SKELETON || head == UMT_HEAD_PREDICT_SCALE, UMT_ERR_INVALID, "head = %d", head);
+  UMT_REQUIRE(n > 0 && bs > 0 && bs <= n && n <= 2 * bs, UMT_ERR_INVALID, "forward: n=%d crops for bs=%d samples", n, bs);
+  UMT_REQUIRE(images && intrinsics && extrinsics && sample_range && memory_idx && use_memory && hand_idx &&
+                  joint_angles && wrist_xfs && sigmas,
+              UMT_ERR_INVALID, "forward: null pointer");
+  UMT_TRY(check_ws("forward", workspace, workspace_bytes, umt_forward_workspace_bytes(n, bs)));
+  Carver cv(workspace, workspace_bytes);
+  BackboneWs bw;
+  HeadWs hw;
+  carve_backbone(cv, n, &bw);
+  carve_head(cv, n, bs, &hw);
+  hipStream_t s = (hipStream_t)stream;
+  const int cs = head == UMT_HEAD_KNOWN_SKELETON ? 80 : 72;
+  UMT_TRY(backbone_rows(m, images, n, bw, s));
+  UMT_TRY(fuse_rows(m, bw.feat, intrinsics, extrinsics, sample_range, n, bs, hw, s));
+  UMT_TRY(launch_gather_cam0(extrinsics, sample_range, n, bs, hw.cam0, s));
+  UMT_CHECK_HIP(hipMemsetAsync(hw.rin, 0, (size_t)bs * 36 * 80 * sizeof(float), s));
+  UMT_TRY(temporal_rows(m, hw.cam0, memory_idx, use_memory, bs, hw, hw.rin, cs, s));
+  UMT_TRY(regress_rows(m, head, skel_axes, skel_rest, n_skel, hw.cam0, hand_idx, bs, hw, joint_angles, wrist_xfs, sigmas,
+                       skel_scales, nullptr, s));
+  return 0;
+}

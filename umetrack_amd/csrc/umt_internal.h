@@ -1,0 +1,106 @@
+// Internal declarations shared by the HIP translation units of libumetrack_hip.so.
+// gfx950 only.  Activations between kernels are channels-last ("pixel rows"):
+// a tensor (n, C, H, W) of the reference is stored as [n*H*W][Cs] floats with
+// Cs = C rounded up to a multiple of 8; channels C..Cs-1 are kept at zero.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/umetrack_hip.h"
+
+namespace umt {
+
+int set_error(int code, const char* fmt, ...);
+
+#define UMT_CHECK_HIP(expr)                                                               \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return umt::set_error(UMT_ERR_HIP, "%s failed: %s (%s:%d)", #expr,                  \
+                            hipGetErrorString(e__), __FILE__, __LINE__);                  \
+  } while (0)
+
+#define UMT_REQUIRE(cond, code, ...)                                                      \
+  do {                                                                                    \
+    if (!(cond)) return umt::set_error(code, __VA_ARGS__);                                \
+  } while (0)
+
+#define UMT_TRY(expr)                                                                     \
+  do {                                                                                    \
+    int rc__ = (expr);                                                                    \
+    if (rc__ != 0) return rc__;                                                           \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// One convolution (1x1 or 3x3, stride 1 or 2, pad = taps==9) with its per-channel epilogue
+//   y = (acc + bias[c]) * scale[c] + shift[c]  (+ residual)  (relu)
+// which is conv bias followed by eval-mode BatchNorm in the reference's operation order.
+struct ConvLayer {
+  int taps = 1;        // 1 or 9
+  int cin = 0, cout = 0;
+  int cin_s = 0;       // channel stride of the input rows  (multiple of 8)
+  int cout_s = 0;      // channel stride of the output rows (multiple of 8)
+  int cout_w = 0;      // cout padded to the 32-wide MFMA tile
+  int stride = 1;
+  int relu = 0;
+  const float* w = nullptr;      // dev, packed [tap][cin_s/8][2][cout_w][4]
+  const float* bias = nullptr;   // dev [cout_w]
+  const float* scale = nullptr;  // dev [cout_w]
+  const float* shift = nullptr;  // dev [cout_w]
+};
+
+// conv_igemm.hip
+int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
+                float* out, hipStream_t stream);
+
+// stem.hip: conv3x3(1->32)+bias+BN+ReLU+maxpool2 ; images (n,96,96) -> rows [n*48*48][32]
+struct StemParams {
+  const float* w;      // dev [9][32]
+  const float* bias;   // dev [32]
+  const float* scale;  // dev [32]
+  const float* shift;  // dev [32]
+};
+int launch_stem(const StemParams& p, const float* images, int n, float* out, hipStream_t stream);
+
+// head.hip
+int launch_rows_to_nchw(const float* rows, int cs, int c0, int c, int n, int hw, float* nchw, hipStream_t s);
+int launch_nchw_to_rows(const float* nchw, int c, int n, int hw, float* rows, int cs, int c0, hipStream_t s);
+int launch_zero_channels(float* rows, int cs, int c0, int c, int64_t nrows, hipStream_t s);
+// per-sample transforms for fusion: to_canon (per crop, 12 floats [R|t] rows) and out_xf (per sample)
+int launch_fusion_xforms(const float* intrinsics, const float* extrinsics, const int64_t* sample_range,
+                         int n, int bs, float* crop_xf, float* sample_xf, int32_t* sample_views,
+                         hipStream_t s);
+int launch_ftl_concat(const float* feat_rows, const float* crop_xf, const int64_t* sample_range,
+                      const int32_t* sample_views, int n, int bs, float* cat_rows, hipStream_t s);
+int launch_ftl_select(const float* conv_rows, const float* feat_rows, const float* sample_xf,
+                      const int64_t* sample_range, const int32_t* sample_views, int n, int bs,
+                      float* out_rows, int out_cs, int out_c0, hipStream_t s);
+// rel_xf: scratch [bs][12] floats, row_of: scratch [bs] int32 (validated memory row per sample)
+int launch_temporal_gather(float* mem, float* prev_ext, int mem_rows, const float* cam0_ext,
+                           const int64_t* memory_idx, const uint8_t* use_memory, int bs,
+                           float* tin_rows, int tin_cs, float* rel_xf, int32_t* row_of, hipStream_t s);
+int launch_temporal_split(const float* tout_rows, int tout_cs, float* mem, const int32_t* row_of, int bs,
+                          float* out_rows, int out_cs, hipStream_t s);
+struct SkelParams {
+  const float* w;      // dev [144][132]
+  const float* bias;   // dev [144]
+  const float* scale;  // dev [4]
+  const float* shift;  // dev [4]
+};
+int launch_skeleton(const SkelParams& p, const float* axes, const float* rest, int n_skel, int bs,
+                    float* rows, int cs, int c0, hipStream_t s);
+int launch_avgpool(const float* rows, int cs, int c, int bs, float* raw, hipStream_t s);
+int launch_decode(const float* raw, int nraw, int predict_scale, const float* cam0_ext,
+                  const int64_t* hand_idx, int bs, float* joint_angles, float* wrist_xfs,
+                  float* sigmas, float* skel_scales, hipStream_t s);
+int launch_gather_cam0(const float* extrinsics, const int64_t* sample_range, int n, int bs,
+                       float* cam0, hipStream_t s);
+
+}  // namespace umt

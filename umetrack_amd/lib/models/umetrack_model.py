@@ -1,0 +1,262 @@
+"""Host side of the network: same call surface as lib/models/umetrack_model.py:21-242.
+
+``UmeTrackModel`` owns an opaque native handle (device weights + temporal state)
+and forwards ``regress_pose_use_skeleton`` / ``regress_pose_pred_skel_scale`` to
+``umt_model_forward``.  All arithmetic happens in hand-written HIP kernels; the
+only torch work here is allocating output and workspace tensors.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ... import _native as nat
+from ... import arch
+from .regressor import RegressorOutput
+
+
+@dataclass
+class InputFrameData:
+    """left_images [n,h,w], intrinsics [n,3,3], extrinsics_xf [n,4,4] (umetrack_model.py:21-35)."""
+    left_images: torch.Tensor
+    intrinsics: torch.Tensor
+    extrinsics_xf: torch.Tensor
+
+
+@dataclass
+class InputFrameDesc:
+    """sample_range [bs,2], memory_idx [bs], use_memory [bs], hand_idx [bs] (umetrack_model.py:40-61)."""
+    sample_range: torch.Tensor
+    memory_idx: torch.Tensor
+    use_memory: torch.Tensor
+    hand_idx: torch.Tensor
+
+
+@dataclass
+class InputSkeletonData:
+    """joint_rotation_axes / joint_rest_positions [bs,22,3] or [22,3] (umetrack_model.py:64-74)."""
+    joint_rotation_axes: torch.Tensor
+    joint_rest_positions: torch.Tensor
+
+
+class UmeTrackModel:
+    """Drop-in for the reference nn.Module (inference only, gfx950 only)."""
+
+    def __init__(self, state_dict: Dict[str, object]):
+        L = nat.lib()
+        self._h = ctypes.c_void_p()
+        nat.check(L.umt_model_create(ctypes.byref(self._h)), "umt_model_create")
+        self._device: Optional[torch.device] = None
+        self._ws = nat.Workspace()
+        self._keep = []
+        self._load_state_dict(state_dict)
+
+    # ---- load_state_dict(strict=True) semantics, model_loader.py:84-88 ----
+    def _load_state_dict(self, sd) -> None:
+        L = nat.lib()
+        expected = arch.state_spec()
+        missing = [k for k in expected if k not in sd]
+        unexpected = [k for k in sd if k not in expected]
+        if missing or unexpected:
+            raise KeyError("Error(s) in loading state_dict: "
+                           + (f"Missing key(s): {missing[:5]}{'...' if len(missing) > 5 else ''} " if missing else "")
+                           + (f"Unexpected key(s): {unexpected[:5]}" if unexpected else ""))
+        for key, (shape, dtype) in expected.items():
+            v = sd[key]
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            if tuple(a.shape) != tuple(shape):
+                raise KeyError(f"Error(s) in loading state_dict: size mismatch for {key}: "
+                               f"{tuple(a.shape)} vs {tuple(shape)}")
+            is_int = dtype == "int64"
+            a = np.array(a, dtype=np.int64 if is_int else np.float32, order="C")   # keeps 0-d scalars 0-d
+            shp = (ctypes.c_int64 * max(1, a.ndim))(*a.shape)
+            nat.check(L.umt_model_set_param(self._h, key.encode(), a.ctypes.data_as(ctypes.c_void_p), a.ndim,
+                                            shp, int(is_int)), f"set_param({key})")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                nat.lib().umt_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- nn.Module-like surface used by the tracker and the eval scripts ----
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise nat.UmtError("umetrack_amd is inference-only")
+        return self
+
+    def to(self, device):
+        dev = nat.require_gpu(device)
+        if self._device is None:
+            with torch.cuda.device(dev):
+                nat.check(nat.lib().umt_model_finalize(self._h, dev.index), "umt_model_finalize")
+            self._device = dev
+        elif dev != self._device:
+            raise nat.UmtError(f"model already lives on {self._device}; create one model per GPU")
+        return self
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
+    @property
+    def device(self) -> Optional[torch.device]:
+        return self._device
+
+    def getInputImageSizes(self) -> Tuple[int, int]:
+        return (arch.CROP_HW, arch.CROP_HW)
+
+    def reset_memory(self) -> None:
+        """Forget the temporal state (a fresh reference model instance starts like this)."""
+        nat.check(nat.lib().umt_model_clear_memory(self._h))
+
+    def memory_state(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Copies of (_mem_features [rows,18,6,6], _prev_extrinsics [rows,4,4]), temporal.py:41-42."""
+        L = nat.lib()
+        rows = ctypes.c_int()
+        nat.check(L.umt_model_memory_rows(self._h, ctypes.byref(rows)))
+        mem = torch.empty(rows.value, arch.N_MEM, 6, 6, dtype=torch.float32, device=self._device)
+        prev = torch.empty(rows.value, 4, 4, dtype=torch.float32, device=self._device)
+        with torch.cuda.device(self._device):
+            nat.check(L.umt_model_read_memory(self._h, nat.ptr(mem), nat.ptr(prev), nat.stream_ptr(self._device)))
+        return mem, prev
+
+    # ---- forward ----
+    def _forward(self, head: int, fd: InputFrameData, desc: InputFrameDesc, skel: Optional[InputSkeletonData],
+                 required_rows: Optional[int] = None) -> RegressorOutput:
+        if self._device is None:
+            self.to(fd.left_images.device if fd.left_images.is_cuda else "cuda")
+        dev, L = self._device, nat.lib()
+        f32, i64 = torch.float32, torch.int64
+        images = nat.dev_tensor(fd.left_images, f32, dev)
+        if images.dim() != 3 or tuple(images.shape[1:]) != (arch.CROP_HW, arch.CROP_HW):
+            raise ValueError(f"left_images must be [n,96,96], got {tuple(images.shape)}")
+        n = images.shape[0]
+        K = nat.dev_tensor(fd.intrinsics, f32, dev)
+        E = nat.dev_tensor(fd.extrinsics_xf, f32, dev)
+        sr = nat.dev_tensor(desc.sample_range, i64, dev)
+        midx = nat.dev_tensor(desc.memory_idx, i64, dev)
+        use = nat.dev_tensor(desc.use_memory, torch.bool, dev).view(torch.uint8)
+        hidx = nat.dev_tensor(desc.hand_idx, i64, dev)
+        bs = sr.shape[0]
+        if tuple(K.shape) != (n, 3, 3) or tuple(E.shape) != (n, 4, 4) or tuple(sr.shape) != (bs, 2) \
+                or midx.numel() != bs or use.numel() != bs or hidx.numel() != bs:
+            raise ValueError("inconsistent InputFrameData / InputFrameDesc shapes")
+        axes = rest = None
+        n_skel = 0
+        if head == nat.HEAD_KNOWN_SKELETON:
+            axes = nat.dev_tensor(skel.joint_rotation_axes, f32, dev).reshape(-1, 22, 3)
+            rest = nat.dev_tensor(skel.joint_rest_positions, f32, dev).reshape(-1, 22, 3)
+            n_skel = axes.shape[0]
+        # temporal.py:102: the memory grows to max(memory_idx)+1 rows (one host sync, as in the reference)
+        if required_rows is None:
+            required_rows = int(midx.max().item()) + 1
+        out = RegressorOutput(
+            joint_angles=torch.empty(bs, 22, dtype=f32, device=dev),
+            wrist_xfs=torch.empty(bs, 4, 4, dtype=f32, device=dev),
+            skel_scales=torch.empty(bs, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
+            landmark_uncertainty_sigmas=torch.empty(bs, 21, dtype=f32, device=dev))
+        nbytes = L.umt_forward_workspace_bytes(n, bs)
+        ws = self._ws.get(dev, nbytes)
+        with torch.cuda.device(dev):
+            st = nat.stream_ptr(dev)
+            nat.check(L.umt_model_reserve_memory(self._h, required_rows, st), "umt_model_reserve_memory")
+            nat.check(L.umt_model_forward(
+                self._h, head, nat.PREC_FP32, nat.ptr(images), nat.ptr(K), nat.ptr(E), nat.ptr(sr), nat.ptr(midx),
+                nat.ptr(use), nat.ptr(hidx), n, bs, nat.ptr(axes), nat.ptr(rest), n_skel,
+                nat.ptr(out.joint_angles), nat.ptr(out.wrist_xfs), nat.ptr(out.landmark_uncertainty_sigmas),
+                nat.ptr(out.skel_scales), nat.ptr(ws), ws.numel(), st), "umt_model_forward")
+        return out
+
+    def regress_pose_use_skeleton(self, frame_data: InputFrameData, frame_desc: InputFrameDesc,
+                                  skel_data: InputSkeletonData, required_rows: Optional[int] = None) -> RegressorOutput:
+        """umetrack_model.py:188-219."""
+        return self._forward(nat.HEAD_KNOWN_SKELETON, frame_data, frame_desc, skel_data, required_rows)
+
+    def regress_pose_pred_skel_scale(self, frame_data: InputFrameData, frame_desc: InputFrameDesc,
+                                     required_rows: Optional[int] = None) -> RegressorOutput:
+        """umetrack_model.py:221-242, including its assertion on single-view samples."""
+        sr = frame_desc.sample_range
+        assert bool(((sr[:, 1] - sr[:, 0]) != 1).all()), \
+            "Unsupported: found single-view samples when calibration scale"
+        return self._forward(nat.HEAD_PREDICT_SCALE, frame_data, frame_desc, None, required_rows)
+
+    # ---- stage-level calls (reference layouts), used by the parity tests ----
+    def backbone(self, images: torch.Tensor) -> torch.Tensor:
+        """_image_backbone(images.unsqueeze(1)), umetrack_model.py:127-129: [n,96,96] -> [n,72,6,6]."""
+        if self._device is None:
+            self.to("cuda")
+        dev, L = self._device, nat.lib()
+        images = nat.dev_tensor(images, torch.float32, dev)
+        n = images.shape[0]
+        out = torch.empty(n, 72, 6, 6, dtype=torch.float32, device=dev)
+        ws = self._ws.get(dev, L.umt_backbone_workspace_bytes(n))
+        with torch.cuda.device(dev):
+            nat.check(L.umt_backbone_forward(self._h, nat.ptr(images), n, nat.PREC_FP32, nat.ptr(out), nat.ptr(ws),
+                                             ws.numel(), nat.stream_ptr(dev)), "umt_backbone_forward")
+        return out
+
+    def fuse_views(self, features, intrinsics, extrinsics, sample_range) -> torch.Tensor:
+        """_forward_feature_extractor after the backbone (umetrack_model.py:130-168)."""
+        dev, L = self._device, nat.lib()
+        f = nat.dev_tensor(features, torch.float32, dev)
+        K = nat.dev_tensor(intrinsics, torch.float32, dev)
+        E = nat.dev_tensor(extrinsics, torch.float32, dev)
+        sr = nat.dev_tensor(sample_range, torch.int64, dev)
+        n, bs = f.shape[0], sr.shape[0]
+        out = torch.empty(bs, 72, 6, 6, dtype=torch.float32, device=dev)
+        ws = self._ws.get(dev, L.umt_head_workspace_bytes(n, bs))
+        with torch.cuda.device(dev):
+            nat.check(L.umt_fuse_views(self._h, nat.ptr(f), nat.ptr(K), nat.ptr(E), nat.ptr(sr), n, bs, nat.ptr(out),
+                                       nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "umt_fuse_views")
+        return out
+
+    def temporal_step(self, fused, cam0_extrinsics, memory_idx, use_memory) -> torch.Tensor:
+        """SimpleConvRNN.forward_temporal_features (temporal.py:93-139)."""
+        dev, L = self._device, nat.lib()
+        f = nat.dev_tensor(fused, torch.float32, dev)
+        E0 = nat.dev_tensor(cam0_extrinsics, torch.float32, dev)
+        midx = nat.dev_tensor(memory_idx, torch.int64, dev)
+        use = nat.dev_tensor(use_memory, torch.bool, dev).view(torch.uint8)
+        bs = f.shape[0]
+        out = torch.empty(bs, 72, 6, 6, dtype=torch.float32, device=dev)
+        ws = self._ws.get(dev, L.umt_head_workspace_bytes(1, bs))
+        with torch.cuda.device(dev):
+            st = nat.stream_ptr(dev)
+            nat.check(L.umt_model_reserve_memory(self._h, int(midx.max().item()) + 1, st))
+            nat.check(L.umt_temporal_step(self._h, nat.ptr(f), nat.ptr(E0), nat.ptr(midx), nat.ptr(use), bs,
+                                          nat.ptr(out), nat.ptr(ws), ws.numel(), st), "umt_temporal_step")
+        return out
+
+    def regress_decode(self, head: int, temporal, cam0_extrinsics, hand_idx, skel: Optional[InputSkeletonData] = None):
+        """Skeleton encoder + PoseRegressor.regress_poses + wrist recovery; returns (RegressorOutput, raw)."""
+        dev, L = self._device, nat.lib()
+        t = nat.dev_tensor(temporal, torch.float32, dev)
+        E0 = nat.dev_tensor(cam0_extrinsics, torch.float32, dev)
+        hidx = nat.dev_tensor(hand_idx, torch.int64, dev)
+        bs = t.shape[0]
+        axes = rest = None
+        n_skel = 0
+        if head == nat.HEAD_KNOWN_SKELETON:
+            axes = nat.dev_tensor(skel.joint_rotation_axes, torch.float32, dev).reshape(-1, 22, 3)
+            rest = nat.dev_tensor(skel.joint_rest_positions, torch.float32, dev).reshape(-1, 22, 3)
+            n_skel = axes.shape[0]
+        f32 = torch.float32
+        out = RegressorOutput(torch.empty(bs, 22, dtype=f32, device=dev), torch.empty(bs, 4, 4, dtype=f32, device=dev),
+                              torch.empty(bs, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
+                              torch.empty(bs, 21, dtype=f32, device=dev))
+        raw = torch.empty(bs, 62 if head == nat.HEAD_KNOWN_SKELETON else 63, dtype=f32, device=dev)
+        ws = self._ws.get(dev, L.umt_head_workspace_bytes(1, bs))
+        with torch.cuda.device(dev):
+            nat.check(L.umt_regress_decode(self._h, head, nat.ptr(t), nat.ptr(axes), nat.ptr(rest), n_skel, nat.ptr(E0),
+                                           nat.ptr(hidx), bs, nat.ptr(out.joint_angles), nat.ptr(out.wrist_xfs),
+                                           nat.ptr(out.landmark_uncertainty_sigmas), nat.ptr(out.skel_scales),
+                                           nat.ptr(raw), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)),
+                      "umt_regress_decode")
+        return out, raw
