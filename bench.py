@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Throughput of the UmeTrack hot path on MI355X: hand-frames/s on the synthetic 4-view x 2-hand
+batch (BASELINE.json configs[2]).
+
+One step = one pass over the whole batch: warp 4-view fisheye frames into 2 crops per hand ->
+network (fp32 MFMA, known-skeleton head) -> forward kinematics of prediction and ground truth ->
+MPJPE/MPJPA/PCK partial sums -> one all-reduce of the 108-word partial vector (RCCL, N>1 only).
+Source frames, cameras and poses are resident in HBM before the timed region.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded by the library
+on the launch stream around the backbone convolutions; `cpu_baseline` times the CPU oracle
+(oracle/, a port of the reference checked against its golden vectors) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from umetrack_amd import arch, dist as udist, synthetic  # noqa: E402
+from umetrack_amd.lib.common import metric_utils as mu  # noqa: E402
+from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_model  # noqa: E402
+from umetrack_amd.lib.common.hand_skinning import skin_landmarks  # noqa: E402
+from umetrack_amd.lib.models.model_loader import model_from_state_dict  # noqa: E402
+from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData  # noqa: E402
+from umetrack_amd.lib.tracker import warp as gpu_warp  # noqa: E402
+
+BACKBONE_FLOP_PER_CROP = 969.23e6      # 484.61 MMAC per 96x96 crop
+MODEL_FLOP_PER_HAND = 1.958e9          # 2 views, known-skeleton head
+FP32_MATRIX_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+class Pipeline:
+    """Device-resident synthetic batch + the per-step driver."""
+
+    def __init__(self, n_frames, T, chunk_frames, seed, device, weight_seed=0):
+        self.dev = device
+        self.hm = load_generic_hand_model()
+        self.model = model_from_state_dict(arch.make_synthetic_state(weight_seed)).to(device)
+
+        def fk(ja, wr, hidx):
+            return skin_landmarks(self.hm, torch.from_numpy(ja), torch.from_numpy(wr),
+                                  hand_idx=torch.from_numpy(hidx), mirror_right=True).cpu().numpy()
+
+        wl = synthetic.make_workload(n_frames, T, seed, self.hm, fk)
+        self.wl = wl
+        d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)  # noqa: E731
+        self.S = wl.joint_angles.shape[0]
+        self.gt_angles, self.gt_wrist = d(wl.joint_angles, torch.float32), d(wl.wrist, torch.float32)
+        self.hand_idx = d(wl.hand_idx, torch.int64)
+        self.src_cams, self.dst_cams = d(wl.src_cams, torch.float64), d(wl.dst_cams, torch.float64)
+        self.src_off, self.src_pitch = d(wl.src_offset, torch.int64), d(wl.src_pitch, torch.int32)
+        self.K, self.E = d(wl.intrinsics, torch.float32), d(wl.extrinsics, torch.float32)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        self.images = torch.randint(0, 256, (wl.image_bytes,), dtype=torch.uint8, device=device, generator=g)
+        hm_m = scaled_hand_model(self.hm, 0.001)
+        self.skel = InputSkeletonData(hm_m.joint_rotation_axes.to(device), hm_m.joint_rest_positions.to(device))
+        # chunks of whole recordings; sample order is [rec][hand][t]
+        assert chunk_frames % T == 0
+        self.chunk = min(chunk_frames, n_frames) * 2           # samples per chunk
+        cs = self.chunk
+        self.sample_range = (torch.arange(cs, device=device)[:, None] * 2 + torch.tensor([0, 2], device=device)).contiguous()
+        self.memory_idx = torch.arange(cs, device=device)
+        self.use_memory = torch.zeros(cs, dtype=torch.bool, device=device)      # throughput mode, section 8(d)
+        self.crops = torch.empty(2 * cs, 96, 96, dtype=torch.float32, device=device)
+        self.pred_lm = torch.empty(wl.n_rec, 2, T, 21, 3, dtype=torch.float32, device=device)
+        self.gt_lm = torch.empty_like(self.pred_lm)
+        self.valid = torch.ones(wl.n_rec, 2, T, dtype=torch.bool, device=device)
+        self.partials = None
+
+    def step(self):
+        cs = self.chunk
+        pred = self.pred_lm.view(-1, 21, 3)
+        gt = self.gt_lm.view(-1, 21, 3)
+        for s0 in range(0, self.S, cs):
+            s1, c0, c1 = s0 + cs, 2 * s0, 2 * (s0 + cs)
+            gpu_warp.warp_crops(self.images, self.src_off[c0:c1], self.src_pitch[c0:c1], self.src_cams[c0:c1],
+                                self.dst_cams[c0:c1], out=self.crops)
+            fd = InputFrameData(self.crops, self.K[c0:c1], self.E[c0:c1])
+            desc = InputFrameDesc(self.sample_range, self.memory_idx, self.use_memory, self.hand_idx[s0:s1])
+            out = self.model.regress_pose_use_skeleton(fd, desc, self.skel, required_rows=cs)
+            skin_landmarks(self.hm, out.joint_angles, out.wrist_xfs, hand_idx=self.hand_idx[s0:s1], mirror_right=True,
+                           wrist_translation_scale=1000.0, out=pred[s0:s1])
+            skin_landmarks(self.hm, self.gt_angles[s0:s1], self.gt_wrist[s0:s1], hand_idx=self.hand_idx[s0:s1],
+                           mirror_right=True, out=gt[s0:s1])
+        self.partials = mu.metric_partials(self.gt_lm, self.pred_lm, self.valid)
+        udist.all_reduce_partials(self.partials)
+        return self.partials
+
+
+def cpu_baseline(pipe, n_hands, budget_s=12.0):
+    """Time the CPU oracle (port of the reference path, pinned to its goldens) on the first
+    `n_hands` samples of the same workload: warp + network + FK + metrics, all host cores torch uses."""
+    from types import SimpleNamespace
+    from oracle import fk as ofk, geometry as og, metrics as omx, model as om
+    wl = pipe.wl
+    n = min(n_hands, pipe.chunk)
+    imgs = pipe.images.cpu().numpy()
+    hm = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in pipe.hm._asdict().items() if v is not None}
+    state = arch.make_synthetic_state(0)
+    frame_bytes = synthetic.SRC_H * synthetic.SRC_W * synthetic.N_VIEWS
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sd = om.to_torch_state(state)
+
+    def one_pass():
+        crops = np.empty((2 * n, 96, 96), np.float32)
+        for k in range(2 * n):
+            sc, dc = wl.src_cams[k], wl.dst_cams[k]
+            frame = imgs[(wl.src_offset[k] // frame_bytes) * frame_bytes:][:frame_bytes].reshape(synthetic.SRC_H, -1)
+            view = frame[:, (wl.src_offset[k] % frame_bytes):][:, :synthetic.SRC_W]
+            src = og.Fisheye62(int(sc[0]), int(sc[1]), (sc[2], sc[3]), (sc[4], sc[5]), list(sc[6:14]), sc[14:].reshape(4, 4))
+            dst = og.Pinhole(96, 96, (dc[0], dc[1]), (dc[2], dc[3]), dc[4:].reshape(4, 4))
+            crops[k] = og.warp_crop(src, dst, np.ascontiguousarray(view))
+        m = om.OracleModel(sd)
+        fd = SimpleNamespace(left_images=torch.from_numpy(crops), intrinsics=torch.from_numpy(wl.intrinsics[:2 * n]),
+                             extrinsics_xf=torch.from_numpy(wl.extrinsics[:2 * n]))
+        desc = SimpleNamespace(sample_range=torch.arange(n)[:, None] * 2 + torch.tensor([0, 2]),
+                               memory_idx=torch.arange(n), use_memory=torch.zeros(n, dtype=torch.bool),
+                               hand_idx=torch.from_numpy(wl.hand_idx[:n]))
+        skel = SimpleNamespace(joint_rotation_axes=torch.from_numpy(hm["joint_rotation_axes"]).float(),
+                               joint_rest_positions=torch.from_numpy(hm["joint_rest_positions"]).float() * 0.001)
+        with torch.no_grad():
+            out = m.regress_pose_use_skeleton(fd, desc, skel)
+        wx = out["wrist_xfs"].numpy().astype(np.float64)
+        wx[:, :3, 3] *= 1000.0
+        wx[wl.hand_idx[:n] == 1, :, 0] *= -1
+        gtw = wl.wrist[:n].astype(np.float64).copy()
+        gtw[wl.hand_idx[:n] == 1, :, 0] *= -1
+        pred = ofk.skin_landmarks(hm, out["joint_angles"].numpy(), wx)
+        gt = ofk.skin_landmarks(hm, wl.joint_angles[:n], gtw)
+        err = np.linalg.norm(gt.astype(np.float64) - pred.astype(np.float64), axis=-1).mean(-1)
+        return pred, float(err.mean())
+
+    t0 = time.perf_counter()
+    pred, mpjpe = one_pass()
+    passes = 1
+    first = time.perf_counter() - t0
+    while time.perf_counter() - t0 + first < budget_s:
+        one_pass()
+        passes += 1
+    dt = (time.perf_counter() - t0) / passes
+    return {"value": n / dt, "unit": "hand-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {n} hand-frames ({2 * n} crops) of the same workload, {passes} pass(es), "
+                      f"oracle warp(cv2 fixed-point)+network fp32+FK, {dt:.2f} s/pass"}, pred, mpjpe
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=4096, help="frames per GPU (weak scaling)")
+    ap.add_argument("--frames-per-recording", type=int, default=64)
+    ap.add_argument("--chunk-frames", type=int, default=512)
+    ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank, world, local = udist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    pipe = Pipeline(args.frames, args.frames_per_recording, args.chunk_frames, seed=rank, device=dev)
+    for _ in range(args.warmup):
+        pipe.step()
+    torch.cuda.synchronize()
+    udist.barrier()
+    pipe.model.timing_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step()
+    torch.cuda.synchronize()
+    udist.barrier()
+    elapsed = udist.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    bb_ms, fwd_ms, calls = pipe.model.timing_read()
+    pipe.model.timing_enable(False)
+
+    hands_per_step = pipe.S * world
+    fin = mu.finalize_partials(pipe.partials)
+    if rank != 0:
+        return
+    crops_per_call = 2 * pipe.chunk
+    achieved = BACKBONE_FLOP_PER_CROP * crops_per_call / (bb_ms / calls * 1e-3) / 1e12
+    line = {
+        "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: synthetic 4-view x 2-hand batch, 4096 frames per GPU, "
+                               "2 crops per hand, fp32 MFMA backbone, known-skeleton head, use_memory=False",
+                   "frames_per_gpu": args.frames, "hand_frames_per_gpu": pipe.S, "crops_per_gpu": 2 * pipe.S,
+                   "source_image": f"{synthetic.SRC_W}x{synthetic.SRC_H} uint8 x {synthetic.N_VIEWS} views",
+                   "chunk_frames": args.chunk_frames, "weights": "seeded random (pretrained_weights.torch not distributed)",
+                   "parallelism": f"frames sharded over {world} GPU(s); all-reduce of 108 float64 metric partials"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "backbone: stem + 27 conv_igemm_f32 launches per forward call",
+                     "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
+                     "forward_avg_ms": fwd_ms / calls, "calls": calls},
+        "model_tflops": MODEL_FLOP_PER_HAND * pipe.S * args.steps / elapsed / 1e12,
+        "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa,
+    }
+    if args.cpu_hands > 0:
+        base, cpu_pred, cpu_mpjpe = cpu_baseline(pipe, args.cpu_hands)
+        line["cpu_baseline"] = base
+        n = cpu_pred.shape[0]
+        gpu_pred = pipe.pred_lm.view(-1, 21, 3)[:n].cpu().numpy()
+        line["parity_sample_max_mm"] = float(np.abs(gpu_pred - cpu_pred).max())
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,13 @@ int umt_model_forward(umt_model* m, int head, int precision, const float* images
                       float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- measurement aid, no counterpart in the reference: when enabled, umt_model_forward records
+ * HIP events on the caller's stream before the backbone, after it and at the end of the call;
+ * umt_model_timing_read waits for them and returns the summed durations since the last enable.
+ * bench.py uses it for the live roofline of the backbone convolutions.                              */
+int umt_model_timing_enable(umt_model* m, int on);
+int umt_model_timing_read(umt_model* m, double* backbone_ms, double* forward_ms, int* calls);
+
 /* ---- A14: skin_landmarks, lib/common/hand_skinning.py:189-209 (+ the right-hand mirror of
  * landmarks_from_hand_pose, lib/tracker/perspective_crop.py:40-51 when mirror_right != 0) ----
  * joint_angles dev f32 (b,22); wrist dev f32 (b,4,4); hand model arrays dev with n_model in {1,b}:

@@ -71,6 +71,10 @@ struct umt_model {
   float* prev_ext = nullptr;   // (rows,4,4)
   int mem_rows = 0;
   int mem_cap = 0;
+  // optional stage timing (umt_model_timing_*): event triples per umt_model_forward call
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;   // 3 per recorded call
+  size_t ev_used = 0;
 };
 
 namespace umt {
@@ -372,6 +376,7 @@ extern "C" int umt_model_destroy(umt_model* m) {
       if (m->slab) (void)hipFree(m->slab);
       if (m->mem) (void)hipFree(m->mem);
       if (m->prev_ext) (void)hipFree(m->prev_ext);
+      for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
       (void)hipSetDevice(prev);
     }
   }
@@ -698,12 +703,50 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
   carve_head(cv, n, bs, &hw);
   hipStream_t s = (hipStream_t)stream;
   const int cs = head == UMT_HEAD_KNOWN_SKELETON ? 80 : 72;
+  hipEvent_t* ev = nullptr;
+  if (m->timing) {
+    while (m->ev_pool.size() < m->ev_used + 3) {
+      hipEvent_t e;
+      UMT_CHECK_HIP(hipEventCreate(&e));
+      m->ev_pool.push_back(e);
+    }
+    ev = &m->ev_pool[m->ev_used];
+    m->ev_used += 3;
+    UMT_CHECK_HIP(hipEventRecord(ev[0], s));
+  }
   UMT_TRY(backbone_rows(m, images, n, bw, s));
+  if (ev) UMT_CHECK_HIP(hipEventRecord(ev[1], s));
   UMT_TRY(fuse_rows(m, bw.feat, intrinsics, extrinsics, sample_range, n, bs, hw, s));
   UMT_TRY(launch_gather_cam0(extrinsics, sample_range, n, bs, hw.cam0, s));
   UMT_CHECK_HIP(hipMemsetAsync(hw.rin, 0, (size_t)bs * 36 * 80 * sizeof(float), s));
   UMT_TRY(temporal_rows(m, hw.cam0, memory_idx, use_memory, bs, hw, hw.rin, cs, s));
   UMT_TRY(regress_rows(m, head, skel_axes, skel_rest, n_skel, hw.cam0, hand_idx, bs, hw, joint_angles, wrist_xfs, sigmas,
                        skel_scales, nullptr, s));
+  if (ev) UMT_CHECK_HIP(hipEventRecord(ev[2], s));
+  return 0;
+}
+
+extern "C" int umt_model_timing_enable(umt_model* m, int on) {
+  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
+  m->timing = on != 0;
+  m->ev_used = 0;
+  return 0;
+}
+
+extern "C" int umt_model_timing_read(umt_model* m, double* backbone_ms, double* forward_ms, int* calls) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(backbone_ms && forward_ms && calls, UMT_ERR_INVALID, "null argument");
+  double b = 0, f = 0;
+  for (size_t i = 0; i + 2 < m->ev_used + 0 && i + 2 < m->ev_pool.size() + 0; i += 3) {
+    float t1 = 0, t2 = 0;
+    UMT_CHECK_HIP(hipEventSynchronize(m->ev_pool[i + 2]));
+    UMT_CHECK_HIP(hipEventElapsedTime(&t1, m->ev_pool[i], m->ev_pool[i + 1]));
+    UMT_CHECK_HIP(hipEventElapsedTime(&t2, m->ev_pool[i], m->ev_pool[i + 2]));
+    b += t1;
+    f += t2;
+  }
+  *backbone_ms = b;
+  *forward_ms = f;
+  *calls = (int)(m->ev_used / 3);
   return 0;
 }

@@ -1,0 +1,69 @@
+"""One process per GPU; the only collective on the hot path is the metric reduction.
+
+Frames / recordings are independent (run_eval_known_skeleton.py:113-115 fans out per
+recording), so ranks never exchange activations.  Each rank reduces its landmarks to the
+108-word partial vector of csrc/metrics.hip and one all-reduce(sum) (RCCL over xGMI on
+GPUs, gloo in CPU tests) combines them - under 1 KB, latency-bound.
+"""
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = None) -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from torchrun's environment; no-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block of items for `rank`; sizes differ by at most one."""
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_recordings(lengths: Sequence[int], world: int) -> List[List[int]]:
+    """Whole recordings per rank (temporal state and MPJPA need a recording on one GPU):
+    longest-first greedy bin packing by frame count."""
+    order = sorted(range(len(lengths)), key=lambda i: -lengths[i])
+    bins: List[List[int]] = [[] for _ in range(world)]
+    load = [0] * world
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        bins[r].append(i)
+        load[r] += lengths[i]
+    return [sorted(b) for b in bins]
+
+
+def all_reduce_partials(partials: torch.Tensor) -> torch.Tensor:
+    """Sum the float64[108] metric partials over all ranks (in place); identity for one process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(partials, op=dist.ReduceOp.SUM)
+    return partials
+
+
+def barrier() -> None:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -14,7 +14,7 @@ from .hand import HandModel
 
 def skin_landmarks(hand_model: HandModel, joint_angles: torch.Tensor, wrist_transforms: torch.Tensor,
                    hand_idx: Optional[torch.Tensor] = None, mirror_right: bool = False,
-                   wrist_translation_scale: float = 1.0) -> torch.Tensor:
+                   wrist_translation_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """joint_angles [...,22], wrist_transforms [...,4,4] -> landmarks [...,21,3] (float32, on the GPU).
 
     Model fields either carry the same leading dims or none (one shared model).
@@ -48,7 +48,10 @@ def skin_landmarks(hand_model: HandModel, joint_angles: torch.Tensor, wrist_tran
                                   for t in (axes, rest, lm, lw, li))
     n_model = axes.shape[0]
     hidx = None if hand_idx is None else nat.dev_tensor(hand_idx, torch.int64, dev).reshape(-1)
-    out = torch.empty(b, 21, 3, dtype=f32, device=dev)
+    if out is None:
+        out = torch.empty(b, 21, 3, dtype=f32, device=dev)
+    else:
+        assert out.is_contiguous() and out.dtype == f32 and out.numel() == b * 63 and out.device == dev
     with torch.cuda.device(dev):
         nat.check(nat.lib().umt_fk_landmarks(nat.ptr(ja), nat.ptr(wr), nat.ptr(axes), nat.ptr(rest), nat.ptr(lm),
                                              nat.ptr(lw), nat.ptr(li), n_model, nat.ptr(hidx), int(mirror_right),

@@ -127,6 +127,16 @@ class UmeTrackModel:
             nat.check(L.umt_model_read_memory(self._h, nat.ptr(mem), nat.ptr(prev), nat.stream_ptr(self._device)))
         return mem, prev
 
+    def timing_enable(self, on: bool = True) -> None:
+        nat.check(nat.lib().umt_model_timing_enable(self._h, int(on)))
+
+    def timing_read(self):
+        """(backbone_ms, forward_ms, calls) summed over the forwards since timing_enable(True)."""
+        b, f, c = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        with torch.cuda.device(self._device):
+            nat.check(nat.lib().umt_model_timing_read(self._h, ctypes.byref(b), ctypes.byref(f), ctypes.byref(c)))
+        return b.value, f.value, c.value
+
     # ---- forward ----
     def _forward(self, head: int, fd: InputFrameData, desc: InputFrameDesc, skel: Optional[InputSkeletonData],
                  required_rows: Optional[int] = None) -> RegressorOutput:

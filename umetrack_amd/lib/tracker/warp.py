@@ -37,7 +37,7 @@ def pack_pinhole(f, c, cam_to_world) -> np.ndarray:
 
 
 def warp_crops(src_images: torch.Tensor, src_offset, src_pitch, src_cams, dst_cams,
-               out_hw=(96, 96), mode: int = MODE_CV2) -> torch.Tensor:
+               out_hw=(96, 96), mode: int = MODE_CV2, out: torch.Tensor = None) -> torch.Tensor:
     """src_images: uint8 device buffer holding every source view; crop k reads the image that
     starts ``src_offset[k]`` bytes into it with row pitch ``src_pitch[k]``.
     src_cams [n,30] / dst_cams [n,20] float64.  Returns float32 [n,H,W] in [0,1]."""
@@ -49,7 +49,10 @@ def warp_crops(src_images: torch.Tensor, src_offset, src_pitch, src_cams, dst_ca
     dc = nat.dev_tensor(dst_cams, torch.float64, dev).reshape(-1, DST_CAM_WORDS)
     n = sc.shape[0]
     assert dc.shape[0] == n and off.numel() == n and pit.numel() == n
-    out = torch.empty(n, out_hw[0], out_hw[1], dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty(n, out_hw[0], out_hw[1], dtype=torch.float32, device=dev)
+    else:
+        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (n, out_hw[0], out_hw[1])
     with torch.cuda.device(dev):
         nat.check(nat.lib().umt_warp_crops(nat.ptr(img), nat.ptr(off), nat.ptr(pit), nat.ptr(sc), nat.ptr(dc), n,
                                            out_hw[0], out_hw[1], mode, nat.ptr(out), nat.stream_ptr(dev)),
