@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU (weak scaling)")
     ap.add_argument("--frames-per-recording", type=int, default=64)
-    ap.add_argument("--chunk-frames", type=int, default=512)
+    ap.add_argument("--chunk-frames", type=int, default=2048)
     ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 

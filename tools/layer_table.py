@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Per-layer backbone table from a rocprofv3 kernel trace of tools/profile_forward.py.
+   python tools/layer_table.py <kernel_trace.csv> [crops]"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+ks = [r for r in rows if "conv" in r["Kernel_Name"] or "stem" in r["Kernel_Name"]]
+ks.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(ks) if "stem" in r["Kernel_Name"]]
+seq = ks[idx[-1]:]
+
+
+def conv(cin, cout, hw, k, stride=1):
+    ho = hw // stride
+    return 2 * cin * cout * k * k * ho * ho
+
+
+L = [("stem", 2 * 9 * 32 * 96 * 96)]
+hw = 48
+for cin, cout, st, nb in [(32, 32, 1, 2), (32, 64, 2, 3), (64, 128, 2, 5), (128, 256, 2, 2)]:
+    for b in range(nb):
+        ci, s = (cin, st) if b == 0 else (cout, 1)
+        L.append((f"c1 {ci}->{cout} hw{hw} s{s}", conv(ci, cout, hw, 3, s)))
+        if b == 0 and st != 1:
+            L.append((f"ds {ci}->{cout}", conv(ci, cout, hw, 1, s)))
+        hw //= s
+        L.append((f"c2 {cout}->{cout} hw{hw}", conv(cout, cout, hw, 3)))
+L.append(("proj", conv(256, 72, 6, 1)))
+tot = 0
+for (name, fl), r in zip(L, seq):
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot += d
+    kn = r["Kernel_Name"].replace("void umt::", "").split("(")[0]
+    print(f"{name:26s} {kn:34s} {d:9.1f} us {fl * n / d / 1e6:7.1f} TF vgpr {r['VGPR_Count']:>4s} lds {r['LDS_Block_Size']}")
+print(f"total {tot / 1e3:.3f} ms -> {sum(f for _, f in L) * n / tot / 1e6:.1f} TFLOP/s")

@@ -16,6 +16,14 @@
 #include "umt_internal.h"
 #include <stdlib.h>
 
+// experiment switches for tools/conv_bench.hip (all off in the library build)
+#ifndef UMT_X_NOMASK
+#define UMT_X_NOMASK 0
+#endif
+#ifndef UMT_X_NOBLOAD
+#define UMT_X_NOBLOAD 0
+#endif
+
 namespace umt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -36,6 +44,49 @@ struct ConvArgs {
 
 constexpr int KC = 32;        // input channels staged per step
 constexpr int LDA = KC + 4;   // padded A row (floats): 16 consecutive pixels hit 16 distinct 16-B slots
+
+
+// Epilogue shared by both kernels.  An accumulator tile has its 32 output channels on the lanes,
+// so storing it directly costs sixteen 4-byte-per-lane instructions per tile (and as many loads
+// for the residual).  Instead each wave transposes the tile through its private 32x36-float LDS
+// patch and then moves whole 128-B rows with 16 bytes per lane: conv bias -> BN scale/shift ->
+// residual -> ReLU are applied on float4s.  Caller guarantees all waves are past their last LDS read.
+__device__ __forceinline__ void store_tile(const f32x16& acc, float* patch, int lane, int mbase, int cobase,
+                                           const ConvArgs& a) {
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDA + li] = acc[r];
+  __builtin_amdgcn_wave_barrier();
+  const int q = lane & 7, rsub = lane >> 3;
+  const int co = cobase + 4 * q;
+  if (co < a.cout_s) {
+    const float4 cb = *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 cs = *reinterpret_cast<const float4*>(a.scale + co);
+    const float4 ch = *reinterpret_cast<const float4*>(a.shift + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 8 * k + rsub;
+      const int m = mbase + row;
+      if (m < a.M) {
+        float4 v = *reinterpret_cast<const float4*>(patch + row * LDA + 4 * q);
+        const size_t o = (size_t)m * a.cout_s + co;
+        v.x = (v.x + cb.x) * cs.x + ch.x;
+        v.y = (v.y + cb.y) * cs.y + ch.y;
+        v.z = (v.z + cb.z) * cs.z + ch.z;
+        v.w = (v.w + cb.w) * cs.w + ch.w;
+        if (a.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(a.residual + o);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(a.out + o) = v;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
@@ -135,28 +186,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
     }
   }
 
-  // ---- epilogue: conv bias -> BN scale/shift -> residual -> ReLU, 128-B row stores ----
+  // ---- epilogue (sA is free: every wave passed the barrier that ended the last MFMA phase) ----
+  float* patch = sA + wave * 32 * LDA;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + (wn * TN + j) * 32 + li;
-    if (co >= a.cout_s) continue;
-    const float cb = a.bias[co], cs = a.scale[co], ch = a.shift[co];
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + (wm * TM + i) * 32 + row;
-        if (m < a.M) {
-          const size_t o = (size_t)m * a.cout_s + co;
-          float v = (acc[i][j][r] + cb) * cs + ch;
-          if (a.residual) v += a.residual[o];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[o] = v;
-        }
-      }
-    }
-  }
+    for (int i = 0; i < TM; ++i)
+      store_tile(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
 }
 
 
@@ -218,40 +254,67 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // B fragment stream: lane (li, lh) reads packed[tap][c8][lh][n0 + col][0..3]
-  const float* wlane = a.w + ((size_t)lh * a.cout_w + n0 + wn * TN * 32 + li) * 4;
-  const size_t w_c8 = (size_t)2 * a.cout_w * 4;          // floats per c8 group
-  const size_t w_tap = (size_t)c8_total * w_c8;          // floats per tap
+  // B fragment stream: lane (li, lh) reads packed[tap][c8][lh][n0 + col][0..3].  The wave-uniform
+  // part of the address stays scalar and the loads are unconditional (a channel group past the
+  // end is clamped to the last one: its A operand is zero-filled, so the product vanishes) - a
+  // predicated load would make hipcc branch around every load and serialise the prefetch.
+  const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 4 * sizeof(float));
+  const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 4);
+  const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float);   // bytes per c8 group
+  const size_t w_tap = (size_t)c8_total * w_c8;                   // bytes per tap
   float4 bcur[4][TN], bnext[4][TN];
   auto load_b = [&](float4 (&dst)[4][TN], int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int c8 = chunk * 4 + c;
+      const int c8 = min(chunk * 4 + c, c8_total - 1);
+      const char* wu = wblock + tap * w_tap + c8 * w_c8;          // wave-uniform
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        dst[c][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c8 < c8_total) dst[c][j] = *reinterpret_cast<const float4*>(wlane + tap * w_tap + c8 * w_c8 + j * 128);
-      }
+      for (int j = 0; j < TN; ++j)
+        dst[c][j] = *reinterpret_cast<const float4*>(wu + j * 512 + wlane_off);
     }
   };
   load_b(bcur, 0, 0);
 
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  // A staging: thread t owns LDS slots idx = t + 256*k (row idx>>3, channel quad idx&7).  Loads are
+  // unconditional at clamped addresses and zeroed afterwards, so they issue back to back; the range
+  // of the NEXT chunk is fetched into registers while this chunk's MFMAs run and written to LDS
+  // after the barrier that retires this chunk's reads.
+  constexpr int NLD = (BM + 2 * 48 + 2 + 31) / 32;     // W <= 48
+  float4 areg[NLD];
+  unsigned aok = 0;                                     // bit k: slot k holds real data (else zero)
+  auto load_a = [&](int chunk) {
     const int c0 = chunk * KC;
-    // ---- stage the pixel range [g0, g0 + rows) x 32 channels ----
-    for (int idx = tid; idx < rows * 8; idx += 256) {
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
       const int r = idx >> 3, q = idx & 7;
       const int g = g0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g >= 0 && g < a.M && (c0 + 4 * q) < a.cin_s)
-        v = *reinterpret_cast<const float4*>(a.in + (size_t)g * a.cin_s + c0 + 4 * q);
-      *reinterpret_cast<float4*>(sA + r * LDA + 4 * q) = v;
+      const bool ok = r < rows && g >= 0 && g < a.M && (c0 + 4 * q) < a.cin_s;
+      const size_t off = ok ? (size_t)g * a.cin_s + c0 + 4 * q : 0;
+      areg[k] = *reinterpret_cast<const float4*>(a.in + off);   // not touched again until the LDS write
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  load_a(0);
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      float4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
     }
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (tap < 8) load_b(bnext, tap + 1, chunk);
-      else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
+      if (!UMT_X_NOBLOAD) {
+        if (tap < 8) load_b(bnext, tap + 1, chunk);
+        else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
+      }
+      if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of this tap's MFMAs
       const int shift = (tap / 3) * W + (tap % 3);   // (ky-1)*W + (kx-1) + (W+1)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -259,7 +322,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           av[i] = *reinterpret_cast<const float4*>(sA + ((wm * TM + i) * 32 + li + shift) * LDA + c * 8 + 4 * lh);
-          if (!((mask[i] >> tap) & 1u)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!UMT_X_NOMASK && !((mask[i] >> tap) & 1u)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -279,27 +342,13 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
     __syncthreads();
   }
 
+  // ---- epilogue ----
+  float* patch = sA + wave * 32 * LDA;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + (wn * TN + j) * 32 + li;
-    if (co >= a.cout_s) continue;
-    const float cb = a.bias[co], cs = a.scale[co], ch = a.shift[co];
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int m = m0 + (wm * TM + i) * 32 + row;
-        if (m < a.M) {
-          const size_t o = (size_t)m * a.cout_s + co;
-          float v = (acc[i][j][r] + cb) * cs + ch;
-          if (a.residual) v += a.residual[o];
-          if (a.relu) v = fmaxf(v, 0.f);
-          a.out[o] = v;
-        }
-      }
-    }
-  }
+    for (int i = 0; i < TM; ++i)
+      store_tile(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
