@@ -20,6 +20,12 @@
 #ifndef UMT_X_NOMASK
 #define UMT_X_NOMASK 0
 #endif
+#ifndef UMT_CFG64
+#define UMT_CFG64 2, 2, 2, 1
+#endif
+#ifndef UMT_CFG32
+#define UMT_CFG32 4, 1, 1, 1
+#endif
 #ifndef UMT_X_NOBLOAD
 #define UMT_X_NOBLOAD 0
 #endif
@@ -390,8 +396,8 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   if (L.taps == 9 && L.stride == 1 && w <= 48 && !force_gather) {
     if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
     else if (L.cout_w == 96) launch_halo<4, 1, 1, 3>(a, stream);
-    else if (L.cout_w == 64) launch_halo<2, 2, 2, 1>(a, stream);
-    else if (L.cout_w == 32) launch_halo<4, 1, 1, 1>(a, stream);
+    else if (L.cout_w == 64) launch_halo<UMT_CFG64>(a, stream);
+    else if (L.cout_w == 32) launch_halo<UMT_CFG32>(a, stream);
     else return set_error(UMT_ERR_INVALID, "conv: unsupported padded cout %d", L.cout_w);
     UMT_CHECK_HIP(hipGetLastError());
     return 0;
