@@ -195,6 +195,12 @@ def main():
     if rank != 0:
         return
     crops_per_call = 2 * pipe.chunk
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_backbone_traffic.json")
+    if os.path.exists(tpath):      # PMC passes cannot run inside this process; see the file for provenance
+        with open(tpath) as fh:
+            tj = json.load(fh)
+        traffic = (tj["read_bytes_per_crop"] + tj["write_bytes_per_crop"]) * crops_per_call
     achieved = BACKBONE_FLOP_PER_CROP * crops_per_call / (bb_ms / calls * 1e-3) / 1e12
     line = {
         "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
@@ -207,7 +213,9 @@ def main():
                    "chunk_frames": args.chunk_frames, "weights": "seeded random (pretrained_weights.torch not distributed)",
                    "parallelism": f"frames sharded over {world} GPU(s); all-reduce of 108 float64 metric partials"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_note": "HBM bytes per forward call from rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
+                                     "profiles/r01_backbone_traffic.json (measured at 2048 crops/call, scaled per crop)",
                      "kernel": "backbone: stem + 27 conv_igemm_f32 launches per forward call",
                      "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
                      "forward_avg_ms": fwd_ms / calls, "calls": calls},
