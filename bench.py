@@ -164,9 +164,14 @@ def main():
     ap.add_argument("--frames-per-recording", type=int, default=64)
     ap.add_argument("--chunk-frames", type=int, default=2048)
     ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: all ranks share cuda:0 (use with --backend gloo on a 1-GPU box)")
     args = ap.parse_args()
 
-    rank, world, local = udist.init_from_env()
+    rank, world, local = udist.init_from_env(args.backend)
+    if args.same_device:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
@@ -190,6 +195,28 @@ def main():
     bb_ms, fwd_ms, calls = pipe.model.timing_read()
     pipe.model.timing_enable(False)
 
+    # second mode of section 8(d): the same batch as 64-frame recordings in lock-step with the temporal
+    # memory ON (bulk backbone, then T sequential memory+regressor steps); per-rank, no collective
+    from umetrack_amd import bulk
+    parity_pred = pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy()   # throughput-mode landmarks
+    runner = bulk.BulkSequenceRunner(pipe.model, pipe.wl.n_rec, pipe.wl.T, chunk_samples=pipe.chunk)
+    rec_valid = pipe.valid.view(-1, pipe.wl.T)
+
+    def recurrent_step():
+        runner.features(pipe.images, pipe.src_off, pipe.src_pitch, pipe.src_cams, pipe.dst_cams, pipe.K, pipe.E)
+        out = runner.run(pipe.E, pipe.hand_idx, pipe.skel, rec_valid)
+        skin_landmarks(pipe.hm, out.joint_angles, out.wrist_xfs, hand_idx=pipe.hand_idx, mirror_right=True,
+                       wrist_translation_scale=1000.0, out=pipe.pred_lm.view(-1, 21, 3))
+        return mu.metric_partials(pipe.gt_lm, pipe.pred_lm, pipe.valid)
+
+    recurrent_step()
+    torch.cuda.synchronize()
+    tr0 = time.perf_counter()
+    rec_partials = recurrent_step()
+    torch.cuda.synchronize()
+    rec_dt = time.perf_counter() - tr0
+    rec_fin = mu.finalize_partials(rec_partials)
+
     hands_per_step = pipe.S * world
     fin = mu.finalize_partials(pipe.partials)
     if rank != 0:
@@ -206,7 +233,7 @@ def main():
         "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[2]: synthetic 4-view x 2-hand batch, 4096 frames per GPU, "
+        "config": {"workload": f"BASELINE.json configs[2]: synthetic 4-view x 2-hand batch, {args.frames} frames per GPU, "
                                "2 crops per hand, fp32 MFMA backbone, known-skeleton head, use_memory=False",
                    "frames_per_gpu": args.frames, "hand_frames_per_gpu": pipe.S, "crops_per_gpu": 2 * pipe.S,
                    "source_image": f"{synthetic.SRC_W}x{synthetic.SRC_H} uint8 x {synthetic.N_VIEWS} views",
@@ -221,13 +248,15 @@ def main():
                      "forward_avg_ms": fwd_ms / calls, "calls": calls},
         "model_tflops": MODEL_FLOP_PER_HAND * pipe.S * args.steps / elapsed / 1e12,
         "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa,
+        "recurrent": {"value_per_gpu": pipe.S / rec_dt, "unit": "hand-frames/s", "ms_per_step": rec_dt * 1e3,
+                      "note": f"{pipe.wl.n_rec} recordings x {pipe.wl.T} frames in lock-step, use_memory=True after "
+                              "frame 0, rank 0 only, 1 timed pass", "mpjpe_mm": rec_fin.mpjpe},
     }
     if args.cpu_hands > 0:
         base, cpu_pred, cpu_mpjpe = cpu_baseline(pipe, args.cpu_hands)
         line["cpu_baseline"] = base
         n = cpu_pred.shape[0]
-        gpu_pred = pipe.pred_lm.view(-1, 21, 3)[:n].cpu().numpy()
-        line["parity_sample_max_mm"] = float(np.abs(gpu_pred - cpu_pred).max())
+        line["parity_sample_max_mm"] = float(np.abs(parity_pred[:n] - cpu_pred).max())
     print(json.dumps(line))
 
 

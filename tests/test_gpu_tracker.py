@@ -156,3 +156,56 @@ def test_recurrent_lockstep_recordings_match_oracle():
     assert mem.shape[0] == bs and n_rec * 2 == bs
     rel = float((mem.cpu() - oracle.state.mem).abs().max() / oracle.state.mem.abs().max())
     assert rel < 2e-4, rel
+
+
+def test_bulk_runner_equals_frame_by_frame(hand_model_np):
+    """Backbone in bulk + lock-step temporal steps == one regress call per frame, and both match the oracle."""
+    from umetrack_amd import bulk
+    from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_model
+    from umetrack_amd.lib.common.hand_skinning import skin_landmarks
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
+    from umetrack_amd.lib.tracker import warp as gpu_warp
+    dev = torch.device("cuda", 0)
+    hm = load_generic_hand_model()
+
+    def fk(ja, wr, hidx):
+        return skin_landmarks(hm, torch.from_numpy(ja), torch.from_numpy(wr), hand_idx=torch.from_numpy(hidx),
+                              mirror_right=True).cpu().numpy()
+    n_rec, T = 3, 5
+    wl = synthetic.make_workload(n_rec * T, T, 7, hm, fk)
+    state = arch.make_synthetic_state(13)
+    model = model_from_state_dict(state).to(dev)
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)  # noqa: E731
+    images = torch.randint(0, 256, (wl.image_bytes,), dtype=torch.uint8, device=dev)
+    off, pit = d(wl.src_offset, torch.int64), d(wl.src_pitch, torch.int32)
+    sc, dc = d(wl.src_cams, torch.float64), d(wl.dst_cams, torch.float64)
+    K, E, hidx = d(wl.intrinsics, torch.float32), d(wl.extrinsics, torch.float32), d(wl.hand_idx, torch.int64)
+    hm_m = scaled_hand_model(hm, 0.001)
+    skel = InputSkeletonData(hm_m.joint_rotation_axes.to(dev), hm_m.joint_rest_positions.to(dev))
+    valid = torch.ones(n_rec * 2, T, dtype=torch.bool, device=dev)
+    valid[1, 2] = False                                             # one hand loses tracking for a frame
+    runner = bulk.BulkSequenceRunner(model, n_rec, T, chunk_samples=8)   # chunking that does not divide S
+    runner.features(images, off, pit, sc, dc, K, E)
+    got = runner.run(E, hidx, skel, valid)
+    # frame-by-frame on a second model instance + the oracle
+    model2 = model_from_state_dict(state).to(dev)
+    oracle = om.OracleModel(state)
+    R = n_rec * 2
+    crops = gpu_warp.warp_crops(images, off, pit, sc, dc)
+    prev_ok = torch.zeros(R, dtype=torch.bool)
+    for t in range(T):
+        idx = torch.arange(R) * T + t
+        cidx = torch.stack([2 * idx, 2 * idx + 1], 1).reshape(-1).to(dev)
+        fd = InputFrameData(crops[cidx], K[cidx], E[cidx])
+        desc = InputFrameDesc(torch.arange(R)[:, None] * 2 + torch.tensor([0, 2]), torch.arange(R), prev_ok,
+                              hidx[idx.to(dev)])
+        ref = model2.regress_pose_use_skeleton(fd, desc, skel)
+        with torch.no_grad():
+            orc = oracle.regress_pose_use_skeleton(fd, desc, skel)
+        keep = valid[:, t].cpu()
+        a = got.wrist_xfs[idx.to(dev)].cpu()[keep]
+        assert torch.equal(a, ref.wrist_xfs.cpu()[keep]), t                       # identical arithmetic
+        assert torch.equal(got.joint_angles[idx.to(dev)].cpu()[keep], ref.joint_angles.cpu()[keep])
+        assert (a[:, :3, 3] - orc["wrist_xfs"][keep][:, :3, 3]).abs().max() < 1e-5
+        prev_ok = valid[:, t].cpu()

@@ -1,0 +1,75 @@
+"""Bulk scheduling of recordings: backbone in bulk, temporal memory in lock-step.
+
+The reference walks a recording frame by frame (run_eval_known_skeleton.py:68-86) although only the
+tiny temporal module (0.87 MMAC per hand, temporal.py:93-139) depends on the previous frame: crop
+cameras come from ground truth, so warp, backbone and view fusion of every frame are independent
+(SURVEY.md section 3.1).  ``BulkSequenceRunner`` therefore
+
+  1. runs warp -> backbone -> fusion over all frames of all recordings in large chunks, and
+  2. steps the temporal memory + regressor once per time index over all (recording, hand) pairs
+     in lock-step, memory row = 2*recording + hand.
+
+Samples are ordered [recording][hand][t] (umetrack_amd.synthetic).  Results equal what the
+frame-by-frame calls produce, because every output pixel is accumulated in the same order whatever
+the batch size.
+"""
+from typing import Optional
+
+import torch
+
+from . import _native as nat
+from .lib.models.regressor import RegressorOutput
+from .lib.models.umetrack_model import InputSkeletonData, UmeTrackModel
+from .lib.tracker import warp as gpu_warp
+
+
+class BulkSequenceRunner:
+    def __init__(self, model: UmeTrackModel, n_rec: int, T: int, chunk_samples: int = 4096):
+        self.model, self.n_rec, self.T = model, n_rec, T
+        self.S = n_rec * 2 * T
+        self.chunk = min(chunk_samples, self.S)
+        dev = model.device
+        self.dev = dev
+        self.fused = torch.empty(self.S, 72, 6, 6, dtype=torch.float32, device=dev)
+        self.crops = torch.empty(2 * self.chunk, 96, 96, dtype=torch.float32, device=dev)
+        rows = torch.arange(n_rec * 2, device=dev)
+        self.memory_idx = rows
+        self.step_index = [rows * T + t for t in range(T)]          # sample ids of time t
+        self.sample_range = (torch.arange(self.chunk, device=dev)[:, None] * 2
+                             + torch.tensor([0, 2], device=dev)).contiguous()
+
+    def features(self, images, src_off, src_pitch, src_cams, dst_cams, K, E, warp_mode=gpu_warp.MODE_CV2):
+        """Phase 1: fused per-sample features [S,72,6,6] (all samples 2-view)."""
+        cs = self.chunk
+        for s0 in range(0, self.S, cs):
+            s1 = min(s0 + cs, self.S)
+            n = s1 - s0
+            c0, c1 = 2 * s0, 2 * s1
+            crops = self.crops[:2 * n]
+            gpu_warp.warp_crops(images, src_off[c0:c1], src_pitch[c0:c1], src_cams[c0:c1], dst_cams[c0:c1],
+                                mode=warp_mode, out=crops)
+            feats = self.model.backbone(crops)
+            self.fused[s0:s1] = self.model.fuse_views(feats, K[c0:c1], E[c0:c1], self.sample_range[:n])
+        return self.fused
+
+    def run(self, E, hand_idx, skel: InputSkeletonData, valid: Optional[torch.Tensor] = None) -> RegressorOutput:
+        """Phase 2: T lock-step temporal + regressor steps.  ``valid`` [n_rec*2, T] marks tracked
+        hand-frames; a hand uses its memory when it was tracked in the previous frame
+        (tracker.py:233-236, 278-285).  Rows of untracked hand-frames are computed but meaningless."""
+        m, T, R = self.model, self.T, self.n_rec * 2
+        m.reset_memory()
+        dev = self.dev
+        out = RegressorOutput(torch.empty(self.S, 22, device=dev), torch.empty(self.S, 4, 4, device=dev), None,
+                              torch.empty(self.S, 21, device=dev))
+        cam0_all = E[0::2]                                   # first crop of every sample
+        prev_ok = torch.zeros(R, dtype=torch.bool, device=dev)
+        for t in range(T):
+            idx = self.step_index[t]
+            cam0 = cam0_all[idx].contiguous()
+            temporal = m.temporal_step(self.fused[idx], cam0, self.memory_idx, prev_ok, required_rows=R)
+            o, _ = m.regress_decode(nat.HEAD_KNOWN_SKELETON, temporal, cam0, hand_idx[idx], skel)
+            out.joint_angles[idx] = o.joint_angles
+            out.wrist_xfs[idx] = o.wrist_xfs
+            out.landmark_uncertainty_sigmas[idx] = o.landmark_uncertainty_sigmas
+            prev_ok = valid[:, t] if valid is not None else torch.ones(R, dtype=torch.bool, device=dev)
+        return out

@@ -24,7 +24,7 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
         kw = {}
         if backend == "nccl":
             torch.cuda.set_device(local)
-            kw["device_id"] = torch.device("cuda", local)
+            kw["device_id"] = torch.device("cuda", local)       # one communicator per GPU, bound early
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 

@@ -227,7 +227,8 @@ class UmeTrackModel:
                                        nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "umt_fuse_views")
         return out
 
-    def temporal_step(self, fused, cam0_extrinsics, memory_idx, use_memory) -> torch.Tensor:
+    def temporal_step(self, fused, cam0_extrinsics, memory_idx, use_memory,
+                      required_rows: Optional[int] = None) -> torch.Tensor:
         """SimpleConvRNN.forward_temporal_features (temporal.py:93-139)."""
         dev, L = self._device, nat.lib()
         f = nat.dev_tensor(fused, torch.float32, dev)
@@ -239,7 +240,8 @@ class UmeTrackModel:
         ws = self._ws.get(dev, L.umt_head_workspace_bytes(1, bs))
         with torch.cuda.device(dev):
             st = nat.stream_ptr(dev)
-            nat.check(L.umt_model_reserve_memory(self._h, int(midx.max().item()) + 1, st))
+            rows = int(midx.max().item()) + 1 if required_rows is None else required_rows
+            nat.check(L.umt_model_reserve_memory(self._h, rows, st))
             nat.check(L.umt_temporal_step(self._h, nat.ptr(f), nat.ptr(E0), nat.ptr(midx), nat.ptr(use), bs,
                                           nat.ptr(out), nat.ptr(ws), ws.numel(), st), "umt_temporal_step")
         return out
