@@ -1,0 +1,108 @@
+"""Edge cases through the C ABI: tile-boundary batch sizes, single crops, error returns, determinism."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from umetrack_amd import _native as nat
+from umetrack_amd import arch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    state = arch.make_synthetic_state(3)
+    return model_from_state_dict(state).to("cuda"), om.to_torch_state(state)
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 57])
+def test_backbone_odd_batch_sizes(pair, n):
+    """Pixel counts that do not fill the 128-pixel GEMM tiles (36*n, 144*n ... rows)."""
+    gm, sd = pair
+    rng = np.random.default_rng(n)
+    img = torch.from_numpy(rng.uniform(0, 1, size=(n, 96, 96)).astype(np.float32))
+    got = gm.backbone(img).cpu()
+    with torch.no_grad():
+        ref = om.backbone(sd, img)
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-4
+    # the same crop gives the same features whatever its position in the batch
+    again = gm.backbone(torch.cat([img[-1:], img])).cpu()
+    assert torch.equal(again[0], got[-1])
+
+
+def test_forward_is_deterministic_and_batch_invariant(pair):
+    from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_model
+    from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
+    gm, _ = pair
+    rng = np.random.default_rng(0)
+    bs = 9
+    img = torch.from_numpy(rng.uniform(0, 1, size=(2 * bs, 96, 96)).astype(np.float32))
+    K = torch.tensor([[300.0, 0, 47.5], [0, 300.0, 47.5], [0, 0, 1]]).repeat(2 * bs, 1, 1)
+    E = torch.eye(4).repeat(2 * bs, 1, 1)
+    E[:, :3, 3] = torch.from_numpy(rng.normal(size=(2 * bs, 3)).astype(np.float32)) * 0.1
+    hm = scaled_hand_model(load_generic_hand_model(), 0.001)
+    skel = InputSkeletonData(hm.joint_rotation_axes, hm.joint_rest_positions)
+
+    def run(sel):
+        c = torch.stack([2 * sel, 2 * sel + 1], 1).reshape(-1)
+        k = len(sel)
+        gm.reset_memory()
+        return gm.regress_pose_use_skeleton(
+            InputFrameData(img[c], K[c], E[c]),
+            InputFrameDesc(torch.arange(k)[:, None] * 2 + torch.tensor([0, 2]), torch.arange(k),
+                           torch.zeros(k, dtype=torch.bool), torch.zeros(k, dtype=torch.long)), skel)
+    full = run(torch.arange(bs))
+    full2 = run(torch.arange(bs))
+    assert torch.equal(full.wrist_xfs, full2.wrist_xfs) and torch.equal(full.joint_angles, full2.joint_angles)
+    part = run(torch.tensor([4, 2]))
+    assert torch.equal(part.wrist_xfs.cpu(), full.wrist_xfs.cpu()[[4, 2]])
+
+
+def test_error_codes_instead_of_faults(pair):
+    gm, _ = pair
+    L = nat.lib()
+    img = torch.zeros(2, 96, 96, device="cuda")
+    out = torch.zeros(2, 72, 6, 6, device="cuda")
+    small = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    st = nat.stream_ptr(gm.device)
+    rc = L.umt_backbone_forward(gm._h, nat.ptr(img), 2, nat.PREC_FP32, nat.ptr(out), nat.ptr(small), small.numel(), st)
+    assert rc == 5 and b"workspace" in L.umt_last_error()
+    ws = torch.empty(L.umt_backbone_workspace_bytes(2), dtype=torch.uint8, device="cuda")
+    rc = L.umt_backbone_forward(gm._h, nat.ptr(img), 2, nat.PREC_BF16 + 7, nat.ptr(out), nat.ptr(ws), ws.numel(), st)
+    assert rc != 0
+    rc = L.umt_backbone_forward(gm._h, nat.ptr(img), 0, nat.PREC_FP32, nat.ptr(out), nat.ptr(ws), ws.numel(), st)
+    assert rc == 1
+    with pytest.raises(ValueError, match="96,96"):
+        gm.backbone(torch.zeros(2, 64, 64))
+    # a model that was never finalized refuses to run
+    h = ctypes.c_void_p()
+    nat.check(L.umt_model_create(ctypes.byref(h)))
+    rc = L.umt_backbone_forward(h, nat.ptr(img), 2, 0, nat.ptr(out), nat.ptr(ws), ws.numel(), st)
+    assert rc == 2 and b"not finalized" in L.umt_last_error()
+    L.umt_model_destroy(h)
+    # malformed sample ranges poison their rows with NaN instead of reading out of bounds
+    feats = torch.zeros(4, 72, 6, 6)
+    K = torch.eye(3).repeat(4, 1, 1) * 200
+    E = torch.eye(4).repeat(4, 1, 1)
+    fused = gm.fuse_views(feats, K, E, torch.tensor([[0, 2], [2, 9]]))
+    assert torch.isfinite(fused[0]).all() and torch.isnan(fused[1]).all()
+    # empty batches are no-ops for the pointwise entry points
+    assert L.umt_fk_landmarks(None, None, None, None, None, None, None, 1, None, 0, ctypes.c_float(1.0), 0, None, st) == 0
+    assert L.umt_warp_crops(None, None, None, None, None, 0, 96, 96, 0, None, st) == 0
+
+
+def test_memory_reserve_grows_and_keeps_rows(pair):
+    gm, _ = pair
+    gm.reset_memory()
+    f = torch.randn(2, 72, 6, 6)
+    E = torch.eye(4).repeat(2, 1, 1)
+    gm.temporal_step(f, E, torch.tensor([0, 1]), torch.tensor([False, False]))
+    mem1, _ = gm.memory_state()
+    gm.temporal_step(f[:1], E[:1], torch.tensor([40]), torch.tensor([False]))       # grows to 41 rows
+    mem2, prev2 = gm.memory_state()
+    assert mem2.shape[0] == 41 and torch.equal(mem2[:2], mem1) and float(mem2[2:40].abs().max()) == 0
+    assert torch.equal(prev2[40].cpu(), torch.eye(4))

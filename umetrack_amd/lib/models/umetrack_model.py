@@ -204,6 +204,8 @@ class UmeTrackModel:
             self.to("cuda")
         dev, L = self._device, nat.lib()
         images = nat.dev_tensor(images, torch.float32, dev)
+        if images.dim() != 3 or tuple(images.shape[1:]) != (arch.CROP_HW, arch.CROP_HW):
+            raise ValueError(f"left_images must be [n,96,96], got {tuple(images.shape)}")
         n = images.shape[0]
         out = torch.empty(n, 72, 6, 6, dtype=torch.float32, device=dev)
         ws = self._ws.get(dev, L.umt_backbone_workspace_bytes(n))
