@@ -38,15 +38,17 @@ from umetrack_amd.lib.tracker import warp as gpu_warp  # noqa: E402
 BACKBONE_FLOP_PER_CROP = 969.23e6      # 484.61 MMAC per 96x96 crop
 MODEL_FLOP_PER_HAND = 1.958e9          # 2 views, known-skeleton head
 FP32_MATRIX_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MATRIX_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 
 
 class Pipeline:
     """Device-resident synthetic batch + the per-step driver."""
 
-    def __init__(self, n_frames, T, chunk_frames, seed, device, weight_seed=0):
+    def __init__(self, n_frames, T, chunk_frames, seed, device, weight_seed=0, precision="fp32"):
         self.dev = device
         self.hm = load_generic_hand_model()
         self.model = model_from_state_dict(arch.make_synthetic_state(weight_seed)).to(device)
+        self.model.precision = precision
 
         def fk(ja, wr, hidx):
             return skin_landmarks(self.hm, torch.from_numpy(ja), torch.from_numpy(wr),
@@ -164,6 +166,8 @@ def main():
     ap.add_argument("--frames-per-recording", type=int, default=64)
     ap.add_argument("--chunk-frames", type=int, default=2048)
     ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
+                    help="backbone arithmetic; fp32 is the reference's and the headline line, bf16 is a separate mode")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: all ranks share cuda:0 (use with --backend gloo on a 1-GPU box)")
@@ -179,7 +183,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    pipe = Pipeline(args.frames, args.frames_per_recording, args.chunk_frames, seed=rank, device=dev)
+    pipe = Pipeline(args.frames, args.frames_per_recording, args.chunk_frames, seed=rank, device=dev,
+                    precision=args.precision)
     for _ in range(args.warmup):
         pipe.step()
     torch.cuda.synchronize()
@@ -229,21 +234,26 @@ def main():
             tj = json.load(fh)
         traffic = (tj["read_bytes_per_crop"] + tj["write_bytes_per_crop"]) * crops_per_call
     achieved = BACKBONE_FLOP_PER_CROP * crops_per_call / (bb_ms / calls * 1e-3) / 1e12
+    bf16 = args.precision == "bf16"
+    peak = BF16_MATRIX_PEAK_TFLOPS if bf16 else FP32_MATRIX_PEAK_TFLOPS
+    if bf16:
+        traffic = None       # the PMC passes on file were taken in fp32 mode
     line = {
         "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2]: synthetic 4-view x 2-hand batch, {args.frames} frames per GPU, "
-                               "2 crops per hand, fp32 MFMA backbone, known-skeleton head, use_memory=False",
+                               f"2 crops per hand, {args.precision} MFMA backbone, known-skeleton head, use_memory=False",
                    "frames_per_gpu": args.frames, "hand_frames_per_gpu": pipe.S, "crops_per_gpu": 2 * pipe.S,
                    "source_image": f"{synthetic.SRC_W}x{synthetic.SRC_H} uint8 x {synthetic.N_VIEWS} views",
                    "chunk_frames": args.chunk_frames, "weights": "seeded random (pretrained_weights.torch not distributed)",
                    "parallelism": f"frames sharded over {world} GPU(s); all-reduce of 108 float64 metric partials"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": traffic,
                      "traffic_note": "HBM bytes per forward call from rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
                                      "profiles/r01_backbone_traffic.json (measured at 2048 crops/call, scaled per crop)",
-                     "kernel": "backbone: stem + 27 conv_igemm_f32 launches per forward call",
+                     "kernel": "backbone: stem + 27 " + ("conv_*_bf16" if bf16 else "conv_igemm_f32 / conv3x3s1_halo_f32")
+                               + " launches per forward call",
                      "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
                      "forward_avg_ms": fwd_ms / calls, "calls": calls},
         "model_tflops": MODEL_FLOP_PER_HAND * pipe.S * args.steps / elapsed / 1e12,

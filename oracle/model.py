@@ -60,6 +60,33 @@ def backbone(sd, images: torch.Tensor) -> torch.Tensor:
     return F.conv2d(x, sd[f"{_BB}.1.weight"], sd[f"{_BB}.1.bias"])
 
 
+def _rb(x: torch.Tensor) -> torch.Tensor:
+    """Round to bfloat16 (nearest even) and return in the original dtype."""
+    return x.to(torch.float32).to(torch.bfloat16).to(x.dtype)
+
+
+def backbone_bf16(sd, images: torch.Tensor) -> torch.Tensor:
+    """The backbone as UMT_PREC_BF16 evaluates it: conv weights and every stored activation
+    (stem output, conv1 output, downsample branch, block output) rounded to bfloat16, wide
+    accumulation, fp32 per-channel epilogue, fp32 projection output.  The reference has no such
+    mode (it runs fp32 throughout); this only checks that the bf16 kernels compute what they
+    claim, and is "parity unpinned" with respect to the reference by construction."""
+    q = {k: (_rb(v) if k.endswith("weight") and v.dim() == 4 and k.startswith(_BB) and ".0._layers.0.0." not in k
+             else v) for k, v in sd.items()}
+    x = images.unsqueeze(1)
+    x = F.conv2d(x, q[f"{_BB}.0._layers.0.0.weight"], q[f"{_BB}.0._layers.0.0.bias"], 1, 1)
+    x = _rb(F.max_pool2d(F.relu(_bn(x, q, f"{_BB}.0._layers.0.1")), 2, 2))
+    for si, ((_, _, stride), nblk) in enumerate(zip(arch.stage_planes(), arch.STAGE_BLOCKS), 1):
+        for b in range(nblk):
+            p, st = f"{_BB}.0._layers.{si}.{b}", (stride if b == 0 else 1)
+            out = _rb(F.relu(_bn(F.conv2d(x, q[f"{p}.conv1.weight"], None, st, 1), q, f"{p}.bn1")))
+            out = _bn(F.conv2d(out, q[f"{p}.conv2.weight"], None, 1, 1), q, f"{p}.bn2")
+            if f"{p}.downsample.0.weight" in q:
+                x = _rb(_bn(F.conv2d(x, q[f"{p}.downsample.0.weight"], None, st, 0), q, f"{p}.downsample.1"))
+            x = _rb(F.relu(out + x))
+    return F.conv2d(x, q[f"{_BB}.1.weight"], q[f"{_BB}.1.bias"])
+
+
 def ftl(xfs: torch.Tensor, fmap: torch.Tensor) -> torch.Tensor:
     """model_utils.py:57-104 with ratio 1.0: channel thirds are X/Y/Z."""
     n = fmap.shape[0]

@@ -1,0 +1,96 @@
+"""UMT_PREC_BF16 backbone (conv_bf16.hip) through the C ABI.
+
+The reference has no reduced-precision mode, so nothing here is pinned to it ("parity unpinned"):
+  * the bf16 kernels are checked against oracle.model.backbone_bf16, a CPU emulation that rounds
+    the same tensors (weights, stored activations) to bfloat16 and accumulates wide.  The two
+    differ only by fp32 accumulation order and the 1-ulp bf16 roundings that order can flip,
+    tolerance 1.5 % of the feature map's max magnitude;
+  * the cost of the mode is stated against the fp32 path on the golden sequence: wrist
+    translation within 1 mm, landmarks within 1.5 mm (fp32 parity mode holds 0.01 mm; bf16 carries
+    8 significant bits through 26 layers).  Use fp32 where the reference's numbers must be met.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model as om
+from umetrack_amd import arch
+from test_gpu_parity import _frame, _rel
+
+pytestmark = pytest.mark.gpu
+
+FEATURE_TOL = 1.5e-2        # relative to max |feature|
+WRIST_TOL_M = 1.0e-3
+ANGLE_TOL_RAD = 2.5e-2
+
+
+@pytest.fixture(scope="module")
+def models(golden_sequence):
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    _, seed = golden_sequence
+    state = arch.make_synthetic_state(seed)
+    gm = model_from_state_dict(state).to("cuda")
+    return gm, state
+
+
+@pytest.mark.parametrize("n", [1, 5, 16])
+def test_bf16_backbone_matches_emulation(models, n):
+    gm, state = models
+    g = torch.Generator().manual_seed(100 + n)
+    img = torch.rand(n, 96, 96, generator=g)
+    gm.precision = "bf16"
+    try:
+        got = gm.backbone(img.cuda()).cpu().numpy()
+    finally:
+        gm.precision = "fp32"
+    sd = om.to_torch_state(state, torch.float64)
+    with torch.no_grad():
+        want = om.backbone_bf16(sd, img.double()).numpy()
+        full = om.backbone(sd, img.double()).numpy()
+    err = _rel(got, want)
+    print(f"bf16 backbone n={n}: vs emulation {err:.2e}, emulation vs fp64 {_rel(want, full):.2e}")
+    assert err < FEATURE_TOL
+    # the mode really runs in reduced precision (guards against silently routing to the fp32 kernels)
+    assert _rel(got, full) > 1e-4
+
+
+def test_bf16_is_deterministic_and_leaves_fp32_untouched(models):
+    gm, _ = models
+    img = torch.rand(6, 96, 96, generator=torch.Generator().manual_seed(7)).cuda()
+    ref32 = gm.backbone(img)
+    gm.precision = "bf16"
+    try:
+        a, b = gm.backbone(img), gm.backbone(img)
+    finally:
+        gm.precision = "fp32"
+    assert torch.equal(a, b)
+    assert torch.equal(gm.backbone(img), ref32)
+    with pytest.raises(ValueError):
+        gm.precision = "fp8"
+
+
+def test_bf16_end_to_end_cost_on_golden_sequence(models, golden_sequence):
+    gm, _ = models
+    steps, _ = golden_sequence
+    worst_t = worst_a = 0.0
+    for prec in ("fp32", "bf16"):
+        gm.reset_memory()
+        gm.precision = prec
+        outs = []
+        try:
+            for st in steps:
+                fd, desc, skel = _frame(st)
+                out = gm.regress_pose_use_skeleton(fd, desc, skel) if skel is not None \
+                    else gm.regress_pose_pred_skel_scale(fd, desc)
+                outs.append((out.joint_angles.cpu().numpy(), out.wrist_xfs.cpu().numpy()))
+        finally:
+            gm.precision = "fp32"
+        if prec == "fp32":
+            base = outs
+    for (ja32, wx32), (ja16, wx16) in zip(base, outs):
+        worst_a = max(worst_a, float(np.abs(ja32 - ja16).max()))
+        worst_t = max(worst_t, float(np.abs(wx32[:, :3, 3] - wx16[:, :3, 3]).max()))
+    print(f"bf16 vs fp32 on the golden sequence: wrist {worst_t * 1e3:.3f} mm, joint angles {worst_a:.2e} rad")
+    assert worst_t < WRIST_TOL_M
+    assert worst_a < ANGLE_TOL_RAD
+    gm.reset_memory()

@@ -1,0 +1,352 @@
+// bf16 variant of the backbone convolutions (UMT_PREC_BF16): bf16 activations and weights,
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16, fp32 epilogue (conv bias -> BN -> residual ->
+// ReLU) rounded once to bf16.  Same two kernel structures as conv_igemm.hip:
+//   * conv_gather_bf16      - any 1x1 / 3x3, stride 1 / 2 (operands staged per tap),
+//   * conv3x3s1_halo_bf16   - stride-1 3x3 with one flattened halo range of pixel rows in LDS
+//                             per 32-channel chunk and weights streamed through registers.
+// Operand map of the 32x32x16 instruction: lane l (r = l&31, h = l>>5) holds A[row r][k = 8h+j]
+// and B[k = 8h+j][col r], j = 0..7, i.e. one 16-byte load of 8 consecutive channels per operand;
+// the packed weights are [tap][cin/16][h][cout32][8] so a B fragment is one 16-byte load too.
+// This path trades the reference's fp32 arithmetic for ~8 bits of mantissa per activation; it is
+// reported separately from the fp32 parity mode (tests/test_gpu_bf16.py states the tolerance).
+#include "umt_internal.h"
+
+namespace umt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgsH {
+  const uint16_t* in;
+  const uint16_t* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const uint16_t* residual;
+  void* out;
+  int out_f32;
+  int H, W, Ho, Wo;
+  int cin_s, cout_s, cout_w;
+  int stride, taps, relu;
+  int M;
+};
+
+constexpr int KCH = 32;          // channels per staged chunk
+constexpr int LDH = 40;          // bf16 per LDS row (80 B): 16 consecutive rows hit 16 distinct 16-B slots
+constexpr int LDP = 36;          // floats per row of the fp32 epilogue patch
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+
+// accumulator tile -> LDS patch (transpose) -> rows of 4 channels per lane
+__device__ __forceinline__ void store_tile_h(const f32x16& acc, float* patch, int lane, int mbase, int cobase,
+                                             const ConvArgsH& a) {
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + li] = acc[r];
+  __builtin_amdgcn_wave_barrier();
+  const int q = lane & 7, rsub = lane >> 3;
+  const int co = cobase + 4 * q;
+  if (co < a.cout_s) {
+    const float4 cb = *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 cs = *reinterpret_cast<const float4*>(a.scale + co);
+    const float4 ch = *reinterpret_cast<const float4*>(a.shift + co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = 8 * k + rsub;
+      const int m = mbase + row;
+      if (m < a.M) {
+        float4 v = *reinterpret_cast<const float4*>(patch + row * LDP + 4 * q);
+        const size_t o = (size_t)m * a.cout_s + co;
+        v.x = (v.x + cb.x) * cs.x + ch.x;
+        v.y = (v.y + cb.y) * cs.y + ch.y;
+        v.z = (v.z + cb.z) * cs.z + ch.z;
+        v.w = (v.w + cb.w) * cs.w + ch.w;
+        if (a.residual) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(a.residual + o);
+          v.x += bf16_lo(rr.x); v.y += bf16_hi(rr.x); v.z += bf16_lo(rr.y); v.w += bf16_hi(rr.y);
+        }
+        if (a.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (a.out_f32)
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = v;
+        else
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + o) =
+              make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------- gather
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_gather_bf16(ConvArgsH a) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  constexpr int A_SLOTS = BM * 4 / 256;       // 16-B slots per thread per step
+  constexpr int A_BYTES = BM * LDH * 2;
+  constexpr int B_BYTES = 4 * BN * 16;        // 2 k16 groups x 2 halves x BN x 16 B
+  constexpr int P_BYTES = 4 * 32 * LDP * 4;
+  constexpr int SMEM = (A_BYTES + B_BYTES) > P_BYTES ? (A_BYTES + B_BYTES) : P_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  unsigned char* sA = smem;
+  unsigned char* sB = smem + A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int pad = a.taps == 9 ? 1 : 0;
+  const int c16_total = a.cin_s >> 4;
+
+  const int ar = tid >> 2, aq = tid & 3;
+  int yi0[A_SLOTS], xi0[A_SLOTS], pixbase[A_SLOTS];
+  bool rowok[A_SLOTS];
+  const int hw_out = a.Ho * a.Wo;
+#pragma unroll
+  for (int r = 0; r < A_SLOTS; ++r) {
+    const int m = m0 + ar + 64 * r;
+    rowok[r] = m < a.M;
+    const int mm = rowok[r] ? m : 0;
+    const int img = mm / hw_out;
+    const int rem = mm - img * hw_out;
+    const int yo = rem / a.Wo, xo = rem - yo * a.Wo;
+    yi0[r] = yo * a.stride - pad;
+    xi0[r] = xo * a.stride - pad;
+    pixbase[r] = img * a.H * a.W;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int tap = 0; tap < a.taps; ++tap) {
+    const int ky = a.taps == 9 ? tap / 3 : 0;
+    const int kx = a.taps == 9 ? tap - 3 * ky : 0;
+    for (int c0 = 0; c0 < a.cin_s; c0 += KCH) {
+      const int kc16 = min(2, c16_total - (c0 >> 4));
+#pragma unroll
+      for (int r = 0; r < A_SLOTS; ++r) {
+        const int yi = yi0[r] + ky, xi = xi0[r] + kx;
+        const bool ok = rowok[r] && yi >= 0 && yi < a.H && xi >= 0 && xi < a.W && (c0 + 8 * aq) < a.cin_s;
+        const size_t off = ok ? (size_t)(pixbase[r] + yi * a.W + xi) * a.cin_s + c0 + 8 * aq : 0;
+        uint4 v = *reinterpret_cast<const uint4*>(a.in + off);
+        if (!ok) v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(sA + ((ar + 64 * r) * LDH + 8 * aq) * 2) = v;
+      }
+      {
+        const uint16_t* wsrc = a.w + ((size_t)tap * c16_total + (c0 >> 4)) * 2 * a.cout_w * 8;
+        for (int idx = tid; idx < kc16 * 2 * BN; idx += 256) {
+          const int row = idx / BN;  // k16l*2 + h
+          const int j = idx - row * BN;
+          *reinterpret_cast<uint4*>(sB + (size_t)idx * 16) =
+              *reinterpret_cast<const uint4*>(wsrc + ((size_t)row * a.cout_w + n0 + j) * 8);
+        }
+      }
+      __syncthreads();
+      for (int k = 0; k < kc16; ++k) {
+        bf16x8 av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          av[i] = *reinterpret_cast<const bf16x8*>(sA + (((wm * TM + i) * 32 + li) * LDH + k * 16 + 8 * lh) * 2);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bv[j] = *reinterpret_cast<const bf16x8*>(sB + ((size_t)(k * 2 + lh) * BN + (wn * TN + j) * 32 + li) * 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  float* patch = reinterpret_cast<float*>(smem) + wave * 32 * LDP;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      store_tile_h(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
+}
+
+// ------------------------------------------------------------------------------------- halo
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sAh[];   // max(rows*80, 4*32*36*4) bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int g0 = m0 - W - 1;
+  const int c16_total = a.cin_s >> 4;
+  const int nchunks = (a.cin_s + KCH - 1) / KCH;
+
+  unsigned mask[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wm * TM + i) * 32 + li;
+    unsigned mk = 0;
+    if (m < a.M) {
+      const int rem = m % (H * W);
+      const int y = rem / W, x = rem - y * W;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << (ky * 3 + kx);
+        }
+    }
+    mask[i] = mk;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 16);
+  const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 8);
+  const size_t w_c16 = (size_t)2 * a.cout_w * 16;       // bytes per 16-channel group
+  const size_t w_tap = (size_t)c16_total * w_c16;
+  uint4 bcur[2][TN], bnext[2][TN];
+  auto load_b = [&](uint4 (&dst)[2][TN], int tap, int chunk) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int c16 = min(chunk * 2 + c, c16_total - 1);
+      const char* wu = wblock + tap * w_tap + c16 * w_c16;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const uint4*>(wu + j * 512 + wlane_off);
+    }
+  };
+  load_b(bcur, 0, 0);
+
+  constexpr int NLD = ((BM + 2 * 48 + 2) * 4 + 255) / 256;
+  uint4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * KCH;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 2, q = idx & 3;
+      const int g = g0 + r;
+      const bool ok = r < rows && g >= 0 && g < a.M && (c0 + 8 * q) < a.cin_s;
+      const size_t off = ok ? (size_t)g * a.cin_s + c0 + 8 * q : 0;
+      areg[k] = *reinterpret_cast<const uint4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  load_a(0);
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      uint4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+      if ((idx >> 2) < rows) *reinterpret_cast<uint4*>(sAh + ((idx >> 2) * LDH + 8 * (idx & 3)) * 2) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) load_b(bnext, tap + 1, chunk);
+      else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
+      if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int shift = (tap / 3) * W + (tap % 3);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        bf16x8 av[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          uint4 raw = *reinterpret_cast<const uint4*>(sAh + (((wm * TM + i) * 32 + li + shift) * LDH + c * 16 + 8 * lh) * 2);
+          if (!((mask[i] >> tap) & 1u)) raw = make_uint4(0, 0, 0, 0);
+          av[i] = __builtin_bit_cast(bf16x8, raw);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bcur[c][j]), acc[i][j], 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bcur[c][j] = bnext[c][j];
+    }
+    __syncthreads();
+  }
+  float* patch = reinterpret_cast<float*>(sAh) + wave * 32 * LDP;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      store_tile_h(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static void launch_gather_h(const ConvArgsH& a, hipStream_t stream) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
+  hipLaunchKernelGGL((conv_gather_bf16<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), 0, stream, a);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static void launch_halo_h(const ConvArgsH& a, hipStream_t stream) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
+  size_t lds = (size_t)(BM + 2 * a.W + 2) * LDH * 2;
+  const size_t patch = (size_t)4 * 32 * LDP * sizeof(float);
+  if (lds < patch) lds = patch;
+  hipLaunchKernelGGL((conv3x3s1_halo_bf16<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), lds, stream, a);
+}
+
+int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual, void* out,
+                     int out_f32, hipStream_t stream) {
+  UMT_REQUIRE(L.wh, UMT_ERR_STATE, "conv_bf16: layer has no bf16 weights");
+  UMT_REQUIRE(L.taps == 1 || L.taps == 9, UMT_ERR_INVALID, "conv_bf16: taps %d", L.taps);
+  UMT_REQUIRE(L.cin_s % 16 == 0 && L.cout_s % 8 == 0 && L.cout_w % 32 == 0, UMT_ERR_INVALID,
+              "conv_bf16: channel strides %d/%d/%d", L.cin_s, L.cout_s, L.cout_w);
+  ConvArgsH a;
+  a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+  a.residual = residual; a.out = out; a.out_f32 = out_f32;
+  a.H = h; a.W = w;
+  const int pad = L.taps == 9 ? 1 : 0, k = L.taps == 9 ? 3 : 1;
+  a.Ho = (h + 2 * pad - k) / L.stride + 1;
+  a.Wo = (w + 2 * pad - k) / L.stride + 1;
+  a.cin_s = L.cin_s; a.cout_s = L.cout_s; a.cout_w = L.cout_w;
+  a.stride = L.stride; a.taps = L.taps; a.relu = L.relu;
+  const int64_t M = (int64_t)n * a.Ho * a.Wo;
+  UMT_REQUIRE(M < (int64_t)1 << 31 && (int64_t)n * h * w < (int64_t)1 << 31, UMT_ERR_INVALID, "conv_bf16: too many pixels");
+  a.M = (int)M;
+  const bool halo = L.taps == 9 && L.stride == 1 && w <= 48;
+  if (L.cout_w % 128 == 0) halo ? launch_halo_h<2, 2, 2, 2>(a, stream) : launch_gather_h<2, 2, 2, 2>(a, stream);
+  else if (L.cout_w == 96) halo ? launch_halo_h<4, 1, 1, 3>(a, stream) : launch_gather_h<4, 1, 1, 3>(a, stream);
+  else if (L.cout_w == 64) halo ? launch_halo_h<2, 2, 2, 1>(a, stream) : launch_gather_h<2, 2, 2, 1>(a, stream);
+  else if (L.cout_w == 32) halo ? launch_halo_h<4, 1, 1, 1>(a, stream) : launch_gather_h<4, 1, 1, 1>(a, stream);
+  else return set_error(UMT_ERR_INVALID, "conv_bf16: unsupported padded cout %d", L.cout_w);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace umt

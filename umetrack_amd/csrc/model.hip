@@ -58,6 +58,7 @@ struct umt_model {
   bool finalized = false;
   int device = -1;
   float* slab = nullptr;   // all packed weights
+  uint16_t* slab_h = nullptr;   // bf16 copies of the backbone conv weights (UMT_PREC_BF16)
   // network
   StemParams stem{};
   std::vector<BlockLayers> blocks;   // 12 backbone blocks
@@ -209,6 +210,40 @@ static void pack_conv(const umt_model* m, std::vector<float>& host, std::vector<
   packed.push_back(p);
 }
 
+// round-to-nearest-even fp32 -> bf16 (the weights are finite)
+static uint16_t to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+// bf16 copy of one conv's weights for conv_bf16.hip:
+//   packed[tap][g][h][co][j] = bf16(W[co][ci = 16*g + 8*h + j][ky][kx])
+struct PackedH {
+  ConvLayer* layer;
+  size_t off;
+};
+static void pack_conv_bf16(const umt_model* m, std::vector<uint16_t>& host, std::vector<PackedH>& packed, ConvLayer* L,
+                           const std::string& wkey) {
+  const std::vector<float>& w = val(m, wkey);
+  const int c16 = L->cin_s / 16;
+  PackedH p{L, host.size()};
+  host.resize(host.size() + (size_t)L->taps * c16 * 2 * L->cout_w * 8, 0);
+  uint16_t* dst = host.data() + p.off;
+  for (int tap = 0; tap < L->taps; ++tap)
+    for (int g = 0; g < c16; ++g)
+      for (int h = 0; h < 2; ++h)
+        for (int co = 0; co < L->cout; ++co)
+          for (int j = 0; j < 8; ++j) {
+            const int ci = 16 * g + 8 * h + j;
+            if (ci < L->cin)
+              dst[((((size_t)tap * c16 + g) * 2 + h) * L->cout_w + co) * 8 + j] =
+                  to_bf16(w[((size_t)co * L->cin + ci) * L->taps + tap]);
+          }
+  packed.push_back(p);
+}
+
 static void pack_block(const umt_model* m, std::vector<float>& host, std::vector<Packed>& packed, BlockLayers* B,
                        const std::string& p, int stride, bool down) {
   pack_conv(m, host, packed, &B->conv1, p + ".conv1.weight", "", p + ".bn1", stride, 1);
@@ -305,6 +340,34 @@ static int backbone_rows(umt_model* m, const float* images, int n, const Backbon
   return 0;
 }
 
+// UMT_PREC_BF16: same schedule on bf16 rows (the fp32 workspace buffers hold them, half used); the
+// projection writes fp32 feature rows so everything after the backbone is unchanged.
+static int backbone_rows_bf16(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
+  uint16_t *x = (uint16_t*)w.a, *t = (uint16_t*)w.b, *y = (uint16_t*)w.c, *d = (uint16_t*)w.d;
+  UMT_TRY(launch_stem_bf16(m->stem, images, n, x, s));
+  for (size_t i = 0; i < m->blocks.size(); ++i) {
+    const BlockLayers& B = m->blocks[i];
+    const int hw = m->block_hw[i];
+    UMT_TRY(launch_conv_bf16(B.conv1, x, n, hw, hw, nullptr, t, 0, s));
+    const uint16_t* res = x;
+    if (B.has_down) {
+      UMT_TRY(launch_conv_bf16(B.down, x, n, hw, hw, nullptr, d, 0, s));
+      res = d;
+    }
+    const int hw2 = hw / B.conv1.stride;
+    UMT_TRY(launch_conv_bf16(B.conv2, t, n, hw2, hw2, res, y, 0, s));
+    uint16_t* old = x;
+    x = y;
+    y = old;
+  }
+  UMT_TRY(launch_conv_bf16(m->proj, x, n, 6, 6, nullptr, w.feat, 1, s));
+  return 0;
+}
+
+static int backbone_any(umt_model* m, int precision, const float* images, int n, const BackboneWs& w, hipStream_t s) {
+  return precision == UMT_PREC_BF16 ? backbone_rows_bf16(m, images, n, w, s) : backbone_rows(m, images, n, w, s);
+}
+
 // feat rows [n*36][72] -> fused features written into tin channels 18..89
 static int fuse_rows(umt_model* m, const float* feat, const float* K, const float* E, const int64_t* sr, int n, int bs,
                      const HeadWs& w, hipStream_t s) {
@@ -374,6 +437,7 @@ extern "C" int umt_model_destroy(umt_model* m) {
     int prev = -1;
     if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(m->device) == hipSuccess) {
       if (m->slab) (void)hipFree(m->slab);
+      if (m->slab_h) (void)hipFree(m->slab_h);
       if (m->mem) (void)hipFree(m->mem);
       if (m->prev_ext) (void)hipFree(m->prev_ext);
       for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
@@ -481,6 +545,20 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
       }
   }
   pack_conv(m, host, packed, &m->proj, bb + ".1.weight", bb + ".1.bias", "", 1, 0);
+  std::vector<uint16_t> host_h;
+  std::vector<PackedH> packed_h;
+  {
+    int bi = 0;
+    for (int s = 0; s < 4; ++s)
+      for (int b = 0; b < N_STAGE_BLOCKS[s]; ++b, ++bi) {
+        const std::string p = bb + ".0._layers." + std::to_string(s + 1) + "." + std::to_string(b);
+        BlockLayers& B = m->blocks[bi];
+        pack_conv_bf16(m, host_h, packed_h, &B.conv1, p + ".conv1.weight");
+        pack_conv_bf16(m, host_h, packed_h, &B.conv2, p + ".conv2.weight");
+        if (B.has_down) pack_conv_bf16(m, host_h, packed_h, &B.down, p + ".downsample.0.weight");
+      }
+    pack_conv_bf16(m, host_h, packed_h, &m->proj, bb + ".1.weight");
+  }
   const std::string fu = "_feature_extractor._multi_view_fusion";
   pack_conv(m, host, packed, &m->fuse1, fu + ".0.weight", fu + ".0.bias", fu + ".1", 1, 1);
   pack_conv(m, host, packed, &m->fuse2, fu + ".3.weight", fu + ".3.bias", fu + ".4", 1, 1);
@@ -527,6 +605,9 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
     p.layer->scale = m->slab + p.s_off;
     p.layer->shift = m->slab + p.h_off;
   }
+  UMT_CHECK_HIP(hipMalloc((void**)&m->slab_h, host_h.size() * sizeof(uint16_t)));
+  UMT_CHECK_HIP(hipMemcpy(m->slab_h, host_h.data(), host_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  for (const PackedH& p : packed_h) p.layer->wh = m->slab_h + p.off;   // every size is a multiple of 8 bf16 = 16 B
   m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3]};
   m->skel = SkelParams{m->slab + sk_off[0], m->slab + sk_off[1], m->slab + sk_off[2], m->slab + sk_off[3]};
   m->device = device;
@@ -613,14 +694,14 @@ static int check_ws(const char* what, void* ws, int64_t have, int64_t need) {
 extern "C" int umt_backbone_forward(umt_model* m, const float* images, int n, int precision, float* features,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
   UMT_TRY(check_ready(m));
-  UMT_REQUIRE(precision == UMT_PREC_FP32, UMT_ERR_UNSUPPORTED, "backbone: only UMT_PREC_FP32 is implemented");
+  UMT_REQUIRE(precision == UMT_PREC_FP32 || precision == UMT_PREC_BF16, UMT_ERR_INVALID, "backbone: precision = %d", precision);
   UMT_REQUIRE(n > 0 && images && features, UMT_ERR_INVALID, "backbone: n=%d or null pointer", n);
   UMT_TRY(check_ws("backbone", workspace, workspace_bytes, umt_backbone_workspace_bytes(n)));
   Carver cv(workspace, workspace_bytes);
   BackboneWs w;
   carve_backbone(cv, n, &w);
   hipStream_t s = (hipStream_t)stream;
-  UMT_TRY(backbone_rows(m, images, n, w, s));
+  UMT_TRY(backbone_any(m, precision, images, n, w, s));
   UMT_TRY(launch_rows_to_nchw(w.feat, 72, 0, 72, n, 36, features, s));
   return 0;
 }
@@ -689,7 +770,7 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
                                  float* wrist_xfs, float* sigmas, float* skel_scales, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
   UMT_TRY(check_ready(m));
-  UMT_REQUIRE(precision == UMT_PREC_FP32, UMT_ERR_UNSUPPORTED, "forward: only UMT_PREC_FP32 is implemented");
+  UMT_REQUIRE(precision == UMT_PREC_FP32 || precision == UMT_PREC_BF16, UMT_ERR_INVALID, "forward: precision = %d", precision);
   UMT_REQUIRE(head == UMT_HEAD_KNOWN_SKELETON || head == UMT_HEAD_PREDICT_SCALE, UMT_ERR_INVALID, "head = %d", head);
   UMT_REQUIRE(n > 0 && bs > 0 && bs <= n && n <= 2 * bs, UMT_ERR_INVALID, "forward: n=%d crops for bs=%d samples", n, bs);
   UMT_REQUIRE(images && intrinsics && extrinsics && sample_range && memory_idx && use_memory && hand_idx &&
@@ -714,7 +795,7 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
     m->ev_used += 3;
     UMT_CHECK_HIP(hipEventRecord(ev[0], s));
   }
-  UMT_TRY(backbone_rows(m, images, n, bw, s));
+  UMT_TRY(backbone_any(m, precision, images, n, bw, s));
   if (ev) UMT_CHECK_HIP(hipEventRecord(ev[1], s));
   UMT_TRY(fuse_rows(m, bw.feat, intrinsics, extrinsics, sample_range, n, bs, hw, s));
   UMT_TRY(launch_gather_cam0(extrinsics, sample_range, n, bs, hw.cam0, s));

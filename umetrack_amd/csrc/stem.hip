@@ -7,8 +7,14 @@
 
 namespace umt {
 
+__device__ __forceinline__ unsigned stem_pack_bf16x2(float a, float b) {
+  const __bf16 x = (__bf16)a, y = (__bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __restrict__ images,
-                                                   int n, float* __restrict__ out) {
+                                                   int n, void* __restrict__ out) {
   __shared__ float sw[9 * 32], sb[32], ss[32], sh[32];
   for (int i = threadIdx.x; i < 9 * 32; i += 256) sw[i] = p.w[i];
   if (threadIdx.x < 32) {
@@ -55,19 +61,35 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __
       }
     res[c] = best;
   }
-  float4* dst = reinterpret_cast<float4*>(out + (size_t)pix * 32 + cg * 8);
-  dst[0] = make_float4(res[0], res[1], res[2], res[3]);
-  dst[1] = make_float4(res[4], res[5], res[6], res[7]);
+  if (OUT_BF16) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + (size_t)pix * 32 + cg * 8) =
+        make_uint4(stem_pack_bf16x2(res[0], res[1]), stem_pack_bf16x2(res[2], res[3]),
+                   stem_pack_bf16x2(res[4], res[5]), stem_pack_bf16x2(res[6], res[7]));
+  } else {
+    float4* dst = reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (size_t)pix * 32 + cg * 8);
+    dst[0] = make_float4(res[0], res[1], res[2], res[3]);
+    dst[1] = make_float4(res[4], res[5], res[6], res[7]);
+  }
 }
 
-int launch_stem(const StemParams& p, const float* images, int n, float* out, hipStream_t stream) {
+template <bool OUT_BF16>
+static int launch_stem_any(const StemParams& p, const float* images, int n, void* out, hipStream_t stream) {
   UMT_REQUIRE(n > 0, UMT_ERR_INVALID, "stem: n = %d", n);
   const int64_t total = (int64_t)n * 48 * 48 * 4;
   const int64_t blocks = (total + 255) / 256;
   UMT_REQUIRE(blocks < ((int64_t)1 << 31), UMT_ERR_INVALID, "stem: batch too large");
-  hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, images, n, out);
+  hipLaunchKernelGGL(stem_kernel<OUT_BF16>, dim3((unsigned)blocks), dim3(256), 0, stream, p, images, n, out);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_stem(const StemParams& p, const float* images, int n, float* out, hipStream_t stream) {
+  return launch_stem_any<false>(p, images, n, out, stream);
+}
+
+// same arithmetic, result rounded once (RNE) to bf16 for the UMT_PREC_BF16 backbone
+int launch_stem_bf16(const StemParams& p, const float* images, int n, uint16_t* out, hipStream_t stream) {
+  return launch_stem_any<true>(p, images, n, out, stream);
 }
 
 }  // namespace umt

@@ -54,11 +54,16 @@ struct ConvLayer {
   const float* bias = nullptr;   // dev [cout_w]
   const float* scale = nullptr;  // dev [cout_w]
   const float* shift = nullptr;  // dev [cout_w]
+  const uint16_t* wh = nullptr;  // dev, bf16 packed [tap][cin_s/16][2][cout_w][8] (backbone layers only)
 };
 
 // conv_igemm.hip
 int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
                 float* out, hipStream_t stream);
+
+// conv_bf16.hip: bf16 rows in, bf16 (or fp32 when out_f32) rows out, fp32 accumulation and epilogue
+int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual,
+                     void* out, int out_f32, hipStream_t stream);
 
 // stem.hip: conv3x3(1->32)+bias+BN+ReLU+maxpool2 ; images (n,96,96) -> rows [n*48*48][32]
 struct StemParams {
@@ -68,6 +73,7 @@ struct StemParams {
   const float* shift;  // dev [32]
 };
 int launch_stem(const StemParams& p, const float* images, int n, float* out, hipStream_t stream);
+int launch_stem_bf16(const StemParams& p, const float* images, int n, uint16_t* out, hipStream_t stream);
 
 // head.hip
 int launch_rows_to_nchw(const float* rows, int cs, int c0, int c, int n, int hw, float* nchw, hipStream_t s);

@@ -51,6 +51,7 @@ class UmeTrackModel:
         self._device: Optional[torch.device] = None
         self._ws = nat.Workspace()
         self._keep = []
+        self._precision = nat.PREC_FP32
         self._load_state_dict(state_dict)
 
     # ---- load_state_dict(strict=True) semantics, model_loader.py:84-88 ----
@@ -108,6 +109,18 @@ class UmeTrackModel:
     @property
     def device(self) -> Optional[torch.device]:
         return self._device
+
+    @property
+    def precision(self) -> str:
+        """"fp32" (default, the reference's arithmetic) or "bf16" (bf16 backbone activations and
+        weights with fp32 accumulation; fusion, temporal memory and the head stay fp32)."""
+        return "bf16" if self._precision == nat.PREC_BF16 else "fp32"
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {value!r}")
+        self._precision = nat.PREC_BF16 if value == "bf16" else nat.PREC_FP32
 
     def getInputImageSizes(self) -> Tuple[int, int]:
         return (arch.CROP_HW, arch.CROP_HW)
@@ -178,7 +191,7 @@ class UmeTrackModel:
             st = nat.stream_ptr(dev)
             nat.check(L.umt_model_reserve_memory(self._h, required_rows, st), "umt_model_reserve_memory")
             nat.check(L.umt_model_forward(
-                self._h, head, nat.PREC_FP32, nat.ptr(images), nat.ptr(K), nat.ptr(E), nat.ptr(sr), nat.ptr(midx),
+                self._h, head, self._precision, nat.ptr(images), nat.ptr(K), nat.ptr(E), nat.ptr(sr), nat.ptr(midx),
                 nat.ptr(use), nat.ptr(hidx), n, bs, nat.ptr(axes), nat.ptr(rest), n_skel,
                 nat.ptr(out.joint_angles), nat.ptr(out.wrist_xfs), nat.ptr(out.landmark_uncertainty_sigmas),
                 nat.ptr(out.skel_scales), nat.ptr(ws), ws.numel(), st), "umt_model_forward")
@@ -210,7 +223,7 @@ class UmeTrackModel:
         out = torch.empty(n, 72, 6, 6, dtype=torch.float32, device=dev)
         ws = self._ws.get(dev, L.umt_backbone_workspace_bytes(n))
         with torch.cuda.device(dev):
-            nat.check(L.umt_backbone_forward(self._h, nat.ptr(images), n, nat.PREC_FP32, nat.ptr(out), nat.ptr(ws),
+            nat.check(L.umt_backbone_forward(self._h, nat.ptr(images), n, self._precision, nat.ptr(out), nat.ptr(ws),
                                              ws.numel(), nat.stream_ptr(dev)), "umt_backbone_forward")
         return out
 
