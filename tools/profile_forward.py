@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 passes: a few whole-model forwards on random crops.
-   rocprofv3 --kernel-trace --stats -- python3 tools/profile_forward.py [crops] [iters]"""
+   rocprofv3 --kernel-trace --stats -- python3 tools/profile_forward.py [crops] [iters] [fp32|bf16]"""
 import os
 import sys
 
@@ -16,6 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
 m = model_from_state_dict(arch.make_synthetic_state(0)).to(dev)
+m.precision = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 bs = n // 2
 g = torch.Generator(device=dev).manual_seed(0)
 fd = InputFrameData(torch.rand(n, 96, 96, device=dev, generator=g),

@@ -100,7 +100,9 @@ __global__ __launch_bounds__(256) void conv_gather_bf16(ConvArgsH a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int li = lane & 31, lh = lane >> 5;
   const int pad = a.taps == 9 ? 1 : 0;
   const int c16_total = a.cin_s >> 4;
@@ -188,7 +190,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int li = lane & 31, lh = lane >> 5;
   const int W = a.W, H = a.H;
   const int rows = BM + 2 * W + 2;

@@ -108,8 +108,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
   const int li = lane & 31, lh = lane >> 5;
   const int pad = a.taps == 9 ? 1 : 0;
   const int c8_total = a.cin_s >> 3;
@@ -223,8 +225,10 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
   const int li = lane & 31, lh = lane >> 5;
   const int W = a.W, H = a.H;
   const int rows = BM + 2 * W + 2;

@@ -39,6 +39,27 @@ int set_error(int code, const char* fmt, ...);
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+#ifdef __HIPCC__
+// Tile owned by this workgroup.  Workgroups are dealt to the 8 XCDs round-robin by linear id, so
+// neighbouring ids sit behind different L2s; this bijective remap gives each XCD label one
+// contiguous run of tiles (cout tile fastest, then pixel tile), so the halo rows two neighbouring
+// pixel tiles share and the activation rows two cout tiles share are fetched into one L2 only.
+// Placement is a speed matter only; nothing depends on it.
+__device__ __forceinline__ void xcd_tile(int& tile_m, int& tile_n) {
+#ifdef UMT_X_NOSWIZZLE
+  tile_m = blockIdx.x;
+  tile_n = blockIdx.y;
+#else
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  const unsigned nwg = gx * gy, lin = blockIdx.y * gx + blockIdx.x;
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = lin & 7u;
+  const unsigned w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lin >> 3);
+  tile_n = (int)(w % gy);
+  tile_m = (int)(w / gy);
+#endif
+}
+#endif
+
 // One convolution (1x1 or 3x3, stride 1 or 2, pad = taps==9) with its per-channel epilogue
 //   y = (acc + bias[c]) * scale[c] + shift[c]  (+ residual)  (relu)
 // which is conv bias followed by eval-mode BatchNorm in the reference's operation order.
