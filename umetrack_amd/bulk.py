@@ -27,20 +27,27 @@ class BulkSequenceRunner:
     def __init__(self, model: UmeTrackModel, n_rec: int, T: int, chunk_samples: int = 4096):
         self.model, self.n_rec, self.T = model, n_rec, T
         self.S = n_rec * 2 * T
-        self.chunk = min(chunk_samples, self.S)
+        # chunks hold whole (recording, hand) rows so that a chunk is a [rows, T] block
+        self.chunk = max(T, min(chunk_samples, self.S) // T * T)
         dev = model.device
         self.dev = dev
-        self.fused = torch.empty(self.S, 72, 6, 6, dtype=torch.float32, device=dev)
+        R = n_rec * 2
+        # phase-1 output in time-major order [T, rows, 72, 6, 6]: a lock-step is one contiguous slice
+        self.fused_t = torch.empty(T, R, 72, 6, 6, dtype=torch.float32, device=dev)
         self.crops = torch.empty(2 * self.chunk, 96, 96, dtype=torch.float32, device=dev)
-        rows = torch.arange(n_rec * 2, device=dev)
-        self.memory_idx = rows
-        self.step_index = [rows * T + t for t in range(T)]          # sample ids of time t
+        self.memory_idx = torch.arange(R, device=dev)
         self.sample_range = (torch.arange(self.chunk, device=dev)[:, None] * 2
                              + torch.tensor([0, 2], device=dev)).contiguous()
+        self._temporal = torch.empty(R, 72, 6, 6, dtype=torch.float32, device=dev)
+
+    @property
+    def fused(self) -> torch.Tensor:
+        """Fused features in sample order [S,72,6,6] (a copy; the runner keeps them time-major)."""
+        return self.fused_t.transpose(0, 1).reshape(self.S, 72, 6, 6)
 
     def features(self, images, src_off, src_pitch, src_cams, dst_cams, K, E, warp_mode=gpu_warp.MODE_CV2):
-        """Phase 1: fused per-sample features [S,72,6,6] (all samples 2-view)."""
-        cs = self.chunk
+        """Phase 1: fused per-sample features (all samples 2-view), stored time-major."""
+        cs, T = self.chunk, self.T
         for s0 in range(0, self.S, cs):
             s1 = min(s0 + cs, self.S)
             n = s1 - s0
@@ -49,8 +56,9 @@ class BulkSequenceRunner:
             gpu_warp.warp_crops(images, src_off[c0:c1], src_pitch[c0:c1], src_cams[c0:c1], dst_cams[c0:c1],
                                 mode=warp_mode, out=crops)
             feats = self.model.backbone(crops)
-            self.fused[s0:s1] = self.model.fuse_views(feats, K[c0:c1], E[c0:c1], self.sample_range[:n])
-        return self.fused
+            fused = self.model.fuse_views(feats, K[c0:c1], E[c0:c1], self.sample_range[:n])
+            self.fused_t[:, s0 // T:s1 // T] = fused.view(n // T, T, 72, 6, 6).transpose(0, 1)
+        return self.fused_t
 
     def run(self, E, hand_idx, skel: InputSkeletonData, valid: Optional[torch.Tensor] = None) -> RegressorOutput:
         """Phase 2: T lock-step temporal + regressor steps.  ``valid`` [n_rec*2, T] marks tracked
@@ -59,17 +67,19 @@ class BulkSequenceRunner:
         m, T, R = self.model, self.T, self.n_rec * 2
         m.reset_memory()
         dev = self.dev
-        out = RegressorOutput(torch.empty(self.S, 22, device=dev), torch.empty(self.S, 4, 4, device=dev), None,
-                              torch.empty(self.S, 21, device=dev))
-        cam0_all = E[0::2]                                   # first crop of every sample
+        # time-major views of the per-sample inputs, built once: no gathers inside the loop
+        cam0_t = E[0::2].view(R, T, 4, 4).transpose(0, 1).contiguous()
+        hand_rows = hand_idx.view(R, T)[:, 0].contiguous()
+        valid_t = valid.t().contiguous() if valid is not None else torch.ones(T, R, dtype=torch.bool, device=dev)
+        ja_t = torch.empty(T, R, 22, device=dev)
+        wx_t = torch.empty(T, R, 4, 4, device=dev)
+        sg_t = torch.empty(T, R, 21, device=dev)
         prev_ok = torch.zeros(R, dtype=torch.bool, device=dev)
         for t in range(T):
-            idx = self.step_index[t]
-            cam0 = cam0_all[idx].contiguous()
-            temporal = m.temporal_step(self.fused[idx], cam0, self.memory_idx, prev_ok, required_rows=R)
-            o, _ = m.regress_decode(nat.HEAD_KNOWN_SKELETON, temporal, cam0, hand_idx[idx], skel)
-            out.joint_angles[idx] = o.joint_angles
-            out.wrist_xfs[idx] = o.wrist_xfs
-            out.landmark_uncertainty_sigmas[idx] = o.landmark_uncertainty_sigmas
-            prev_ok = valid[:, t] if valid is not None else torch.ones(R, dtype=torch.bool, device=dev)
-        return out
+            temporal = m.temporal_step(self.fused_t[t], cam0_t[t], self.memory_idx, prev_ok, required_rows=R,
+                                       out=self._temporal)
+            m.regress_decode(nat.HEAD_KNOWN_SKELETON, temporal, cam0_t[t], hand_rows, skel,
+                             out=RegressorOutput(ja_t[t], wx_t[t], None, sg_t[t]), want_raw=False)
+            prev_ok = valid_t[t]
+        return RegressorOutput(ja_t.transpose(0, 1).reshape(self.S, 22), wx_t.transpose(0, 1).reshape(self.S, 4, 4), None,
+                               sg_t.transpose(0, 1).reshape(self.S, 21))

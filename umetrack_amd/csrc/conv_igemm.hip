@@ -29,6 +29,12 @@
 #ifndef UMT_X_NOBLOAD
 #define UMT_X_NOBLOAD 0
 #endif
+#ifndef UMT_X_NOALOAD
+#define UMT_X_NOALOAD 0
+#endif
+#ifndef UMT_X_NOSTORE
+#define UMT_X_NOSTORE 0
+#endif
 
 namespace umt {
 
@@ -87,7 +93,7 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, float* patch, int 
         if (a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        *reinterpret_cast<float4*>(a.out + o) = v;
+        if (!UMT_X_NOSTORE || v.x == 123.456f) *reinterpret_cast<float4*>(a.out + o) = v;
       }
     }
   }
@@ -302,7 +308,8 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
       const int g = g0 + r;
       const bool ok = r < rows && g >= 0 && g < a.M && (c0 + 4 * q) < a.cin_s;
       const size_t off = ok ? (size_t)g * a.cin_s + c0 + 4 * q : 0;
-      areg[k] = *reinterpret_cast<const float4*>(a.in + off);   // not touched again until the LDS write
+      if (UMT_X_NOALOAD) areg[k] = make_float4(1.f, 2.f, 3.f, 4.f);
+      else areg[k] = *reinterpret_cast<const float4*>(a.in + off);   // not touched again until the LDS write
       aok |= (ok ? 1u : 0u) << k;
     }
   };

@@ -6,6 +6,7 @@
 
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace umt {
 
@@ -318,17 +319,18 @@ static int check_ready(const umt_model* m) {
 }
 
 // ---- stages on channels-last rows ----
-static int backbone_rows(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
-  UMT_TRY(launch_stem(m->stem, images, n, w.a, s));
-  float *x = w.a, *t = w.b, *y = w.c;
-  for (size_t i = 0; i < m->blocks.size(); ++i) {
+// Blocks [b0, b1) on n crops whose rows start at x; returns the buffer that holds the result.
+// x/t/y rotate; the down-sample branch goes to d.
+static int run_blocks(umt_model* m, size_t b0, size_t b1, int n, float*& x, float*& t, float*& y, float* d,
+                      hipStream_t s) {
+  for (size_t i = b0; i < b1; ++i) {
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
     UMT_TRY(launch_conv(B.conv1, x, n, hw, hw, nullptr, t, s));
     const float* res = x;
     if (B.has_down) {
-      UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, w.d, s));
-      res = w.d;
+      UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, d, s));
+      res = d;
     }
     const int hw2 = hw / B.conv1.stride;
     UMT_TRY(launch_conv(B.conv2, t, n, hw2, hw2, res, y, s));
@@ -336,16 +338,47 @@ static int backbone_rows(umt_model* m, const float* images, int n, const Backbon
     x = y;
     y = old;
   }
+  return 0;
+}
+
+static int stage1_sub() {
+  static const int v = getenv("UMT_STAGE1_SUB") ? atoi(getenv("UMT_STAGE1_SUB")) : 0;
+  return v;
+}
+
+static int backbone_rows(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
+  float *x = w.a, *t = w.b, *y = w.c;
+  const int sub = stage1_sub();
+  size_t first = 0;
+  if (sub > 0 && sub < n) {
+    // Stage 1 (stem + 2 blocks at 48x48x32, 295 KB per crop per tensor) depth-first over groups of
+    // `sub` crops, so that a group's three live tensors stay in the 256 MB Infinity Cache between
+    // its five launches instead of streaming 1.2 GB per layer through HBM.
+    const size_t nb1 = (size_t)N_STAGE_BLOCKS[0];
+    float *xe = x, *te = t, *ye = y;
+    for (int c0 = 0; c0 < n; c0 += sub) {
+      const int nc = n - c0 < sub ? n - c0 : sub;
+      const size_t off = (size_t)c0 * ACT_FLOATS;
+      float *xs = w.a + off, *ts = w.b + off, *ys = w.c + off;
+      UMT_TRY(launch_stem(m->stem, images + (size_t)c0 * 96 * 96, nc, xs, s));
+      UMT_TRY(run_blocks(m, 0, nb1, nc, xs, ts, ys, w.d, s));
+      xe = xs - off; te = ts - off; ye = ys - off;    // same rotation for every group
+    }
+    x = xe; t = te; y = ye;
+    first = nb1;
+  } else {
+    UMT_TRY(launch_stem(m->stem, images, n, x, s));
+  }
+  UMT_TRY(run_blocks(m, first, m->blocks.size(), n, x, t, y, w.d, s));
   UMT_TRY(launch_conv(m->proj, x, n, 6, 6, nullptr, w.feat, s));
   return 0;
 }
 
 // UMT_PREC_BF16: same schedule on bf16 rows (the fp32 workspace buffers hold them, half used); the
 // projection writes fp32 feature rows so everything after the backbone is unchanged.
-static int backbone_rows_bf16(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
-  uint16_t *x = (uint16_t*)w.a, *t = (uint16_t*)w.b, *y = (uint16_t*)w.c, *d = (uint16_t*)w.d;
-  UMT_TRY(launch_stem_bf16(m->stem, images, n, x, s));
-  for (size_t i = 0; i < m->blocks.size(); ++i) {
+static int run_blocks_bf16(umt_model* m, size_t b0, size_t b1, int n, uint16_t*& x, uint16_t*& t, uint16_t*& y,
+                           uint16_t* d, hipStream_t s) {
+  for (size_t i = b0; i < b1; ++i) {
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
     UMT_TRY(launch_conv_bf16(B.conv1, x, n, hw, hw, nullptr, t, 0, s));
@@ -360,6 +393,30 @@ static int backbone_rows_bf16(umt_model* m, const float* images, int n, const Ba
     x = y;
     y = old;
   }
+  return 0;
+}
+
+static int backbone_rows_bf16(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
+  uint16_t *x = (uint16_t*)w.a, *t = (uint16_t*)w.b, *y = (uint16_t*)w.c, *d = (uint16_t*)w.d;
+  const int sub = stage1_sub();
+  size_t first = 0;
+  if (sub > 0 && sub < n) {
+    const size_t nb1 = (size_t)N_STAGE_BLOCKS[0];
+    uint16_t *xe = x, *te = t, *ye = y;
+    for (int c0 = 0; c0 < n; c0 += sub) {
+      const int nc = n - c0 < sub ? n - c0 : sub;
+      const size_t off = (size_t)c0 * ACT_FLOATS;
+      uint16_t *xs = x + off, *ts = t + off, *ys = y + off;
+      UMT_TRY(launch_stem_bf16(m->stem, images + (size_t)c0 * 96 * 96, nc, xs, s));
+      UMT_TRY(run_blocks_bf16(m, 0, nb1, nc, xs, ts, ys, d, s));
+      xe = xs - off; te = ts - off; ye = ys - off;
+    }
+    x = xe; t = te; y = ye;
+    first = nb1;
+  } else {
+    UMT_TRY(launch_stem_bf16(m->stem, images, n, x, s));
+  }
+  UMT_TRY(run_blocks_bf16(m, first, m->blocks.size(), n, x, t, y, d, s));
   UMT_TRY(launch_conv_bf16(m->proj, x, n, 6, 6, nullptr, w.feat, 1, s));
   return 0;
 }

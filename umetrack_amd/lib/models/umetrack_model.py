@@ -243,7 +243,7 @@ class UmeTrackModel:
         return out
 
     def temporal_step(self, fused, cam0_extrinsics, memory_idx, use_memory,
-                      required_rows: Optional[int] = None) -> torch.Tensor:
+                      required_rows: Optional[int] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """SimpleConvRNN.forward_temporal_features (temporal.py:93-139)."""
         dev, L = self._device, nat.lib()
         f = nat.dev_tensor(fused, torch.float32, dev)
@@ -251,7 +251,8 @@ class UmeTrackModel:
         midx = nat.dev_tensor(memory_idx, torch.int64, dev)
         use = nat.dev_tensor(use_memory, torch.bool, dev).view(torch.uint8)
         bs = f.shape[0]
-        out = torch.empty(bs, 72, 6, 6, dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty(bs, 72, 6, 6, dtype=torch.float32, device=dev)
         ws = self._ws.get(dev, L.umt_head_workspace_bytes(1, bs))
         with torch.cuda.device(dev):
             st = nat.stream_ptr(dev)
@@ -261,8 +262,10 @@ class UmeTrackModel:
                                           nat.ptr(out), nat.ptr(ws), ws.numel(), st), "umt_temporal_step")
         return out
 
-    def regress_decode(self, head: int, temporal, cam0_extrinsics, hand_idx, skel: Optional[InputSkeletonData] = None):
-        """Skeleton encoder + PoseRegressor.regress_poses + wrist recovery; returns (RegressorOutput, raw)."""
+    def regress_decode(self, head: int, temporal, cam0_extrinsics, hand_idx, skel: Optional[InputSkeletonData] = None,
+                       out: Optional[RegressorOutput] = None, want_raw: bool = True):
+        """Skeleton encoder + PoseRegressor.regress_poses + wrist recovery; returns (RegressorOutput, raw).
+        `out` may hold preallocated contiguous outputs (e.g. slices of a [T, rows, ...] buffer)."""
         dev, L = self._device, nat.lib()
         t = nat.dev_tensor(temporal, torch.float32, dev)
         E0 = nat.dev_tensor(cam0_extrinsics, torch.float32, dev)
@@ -275,10 +278,11 @@ class UmeTrackModel:
             rest = nat.dev_tensor(skel.joint_rest_positions, torch.float32, dev).reshape(-1, 22, 3)
             n_skel = axes.shape[0]
         f32 = torch.float32
-        out = RegressorOutput(torch.empty(bs, 22, dtype=f32, device=dev), torch.empty(bs, 4, 4, dtype=f32, device=dev),
-                              torch.empty(bs, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
-                              torch.empty(bs, 21, dtype=f32, device=dev))
-        raw = torch.empty(bs, 62 if head == nat.HEAD_KNOWN_SKELETON else 63, dtype=f32, device=dev)
+        if out is None:
+            out = RegressorOutput(torch.empty(bs, 22, dtype=f32, device=dev), torch.empty(bs, 4, 4, dtype=f32, device=dev),
+                                  torch.empty(bs, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
+                                  torch.empty(bs, 21, dtype=f32, device=dev))
+        raw = torch.empty(bs, 62 if head == nat.HEAD_KNOWN_SKELETON else 63, dtype=f32, device=dev) if want_raw else None
         ws = self._ws.get(dev, L.umt_head_workspace_bytes(1, bs))
         with torch.cuda.device(dev):
             nat.check(L.umt_regress_decode(self._h, head, nat.ptr(t), nat.ptr(axes), nat.ptr(rest), n_skel, nat.ptr(E0),
