@@ -2,7 +2,8 @@
 """Throughput of the UmeTrack hot path on MI355X: hand-frames/s on the synthetic 4-view x 2-hand
 batch (BASELINE.json configs[2]).
 
-One step = one pass over the whole batch: warp 4-view fisheye frames into 2 crops per hand ->
+One step = one pass over the whole batch: crop cameras from the hand poses (FK of 3 poses + look-at
+geometry, on the device) -> warp 4-view fisheye frames into 2 crops per hand ->
 network (fp32 MFMA, known-skeleton head) -> forward kinematics of prediction and ground truth ->
 MPJPE/MPJPA/PCK partial sums -> one all-reduce of the 108-word partial vector (RCCL, N>1 only).
 Source frames, cameras and poses are resident in HBM before the timed region.
@@ -33,6 +34,7 @@ from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_mo
 from umetrack_amd.lib.common.hand_skinning import skin_landmarks  # noqa: E402
 from umetrack_amd.lib.models.model_loader import model_from_state_dict  # noqa: E402
 from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData  # noqa: E402
+from umetrack_amd.lib.tracker import crop_cameras as gpu_crop  # noqa: E402
 from umetrack_amd.lib.tracker import warp as gpu_warp  # noqa: E402
 
 BACKBONE_FLOP_PER_CROP = 969.23e6      # 484.61 MMAC per 96x96 crop
@@ -44,8 +46,10 @@ BF16_MATRIX_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: v_mfma_f32_32x32x1
 class Pipeline:
     """Device-resident synthetic batch + the per-step driver."""
 
-    def __init__(self, n_frames, T, chunk_frames, seed, device, weight_seed=0, precision="fp32"):
+    def __init__(self, n_frames, T, chunk_frames, seed, device, weight_seed=0, precision="fp32",
+                 host_crop_cameras=False):
         self.dev = device
+        self.host_crop_cameras = host_crop_cameras
         self.hm = load_generic_hand_model()
         self.model = model_from_state_dict(arch.make_synthetic_state(weight_seed)).to(device)
         self.model.precision = precision
@@ -63,6 +67,11 @@ class Pipeline:
         self.src_cams, self.dst_cams = d(wl.src_cams, torch.float64), d(wl.dst_cams, torch.float64)
         self.src_off, self.src_pitch = d(wl.src_offset, torch.int64), d(wl.src_pitch, torch.int32)
         self.K, self.E = d(wl.intrinsics, torch.float32), d(wl.extrinsics, torch.float32)
+        # rig description for the on-device crop-camera generation (row A0): 4 fisheye cameras, no roll,
+        # and the two views the workload assigns to each hand (section 8d forces exactly 2)
+        self.rig_cams = d(wl.rig_cams, torch.float64)
+        self.rig_angles = torch.zeros(synthetic.N_VIEWS, dtype=torch.float64, device=device)
+        self.views = d(wl.views, torch.int32)
         g = torch.Generator(device=device)
         g.manual_seed(seed)
         self.images = torch.randint(0, 256, (wl.image_bytes,), dtype=torch.uint8, device=device, generator=g)
@@ -87,9 +96,17 @@ class Pipeline:
         gt = self.gt_lm.view(-1, 21, 3)
         for s0 in range(0, self.S, cs):
             s1, c0, c1 = s0 + cs, 2 * s0, 2 * (s0 + cs)
+            if self.host_crop_cameras:          # crop cameras precomputed on the host at set-up
+                dst, K, E = self.dst_cams[c0:c1], self.K[c0:c1], self.E[c0:c1]
+            else:                               # A0 on the device: FK of 3 poses -> look-at crop cameras -> K, E
+                pts = gpu_crop.crop_points_batched(self.hm, self.gt_angles[s0:s1], self.gt_wrist[s0:s1],
+                                                   self.hand_idx[s0:s1], 63)
+                cams = gpu_crop.gen_crop_cameras_batched(pts, self.rig_cams, self.rig_angles, self.hand_idx[s0:s1],
+                                                         forced_views=self.views[s0:s1])
+                dst, K, E = cams.dst_cams.view(-1, 20), cams.intrinsics.view(-1, 3, 3), cams.extrinsics.view(-1, 4, 4)
             gpu_warp.warp_crops(self.images, self.src_off[c0:c1], self.src_pitch[c0:c1], self.src_cams[c0:c1],
-                                self.dst_cams[c0:c1], out=self.crops)
-            fd = InputFrameData(self.crops, self.K[c0:c1], self.E[c0:c1])
+                                dst, out=self.crops)
+            fd = InputFrameData(self.crops, K, E)
             desc = InputFrameDesc(self.sample_range, self.memory_idx, self.use_memory, self.hand_idx[s0:s1])
             out = self.model.regress_pose_use_skeleton(fd, desc, self.skel, required_rows=cs)
             skin_landmarks(self.hm, out.joint_angles, out.wrist_xfs, hand_idx=self.hand_idx[s0:s1], mirror_right=True,
@@ -168,6 +185,8 @@ def main():
     ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="backbone arithmetic; fp32 is the reference's and the headline line, bf16 is a separate mode")
+    ap.add_argument("--host-crop-cameras", action="store_true",
+                    help="use crop cameras precomputed on the host instead of generating them on the GPU each step")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: all ranks share cuda:0 (use with --backend gloo on a 1-GPU box)")
@@ -184,7 +203,7 @@ def main():
     dev = torch.device("cuda", local)
 
     pipe = Pipeline(args.frames, args.frames_per_recording, args.chunk_frames, seed=rank, device=dev,
-                    precision=args.precision)
+                    precision=args.precision, host_crop_cameras=args.host_crop_cameras)
     for _ in range(args.warmup):
         pipe.step()
     torch.cuda.synchronize()

@@ -71,6 +71,33 @@ int64_t umt_backbone_workspace_bytes(int n_crops);
 int64_t umt_head_workspace_bytes(int n_crops, int n_samples);
 int64_t umt_forward_workspace_bytes(int n_crops, int n_samples);
 
+/* ---- A0 (F1): crop cameras for a batch of hands, gen_crop_cameras_from_pose,
+ * lib/tracker/perspective_crop.py:54-162 + lib/common/crop.py:15-82 + lib/common/affine.py:34-66,
+ * and the per-crop packing of HandTracker._make_inputs, lib/tracker/tracker.py:212-216 ----
+ * points        dev float32 (n_hands, n_points, 3): crop points in world mm, n_points in 21..63; the
+ *               first 21 are the tracked pose's landmarks (visibility test), the rest the neutral and
+ *               open pose (umt_fk_landmarks output for the three poses of perspective_crop.py:89-115)
+ * cameras       dev float64 (n_rigs, n_rig_views, 30): fisheye cameras in umt_warp_crops' src_cams format
+ * camera_angles dev float64 (n_rigs, n_rig_views): roll in degrees
+ * rig_idx       dev int32 (n_hands) or NULL (one rig)
+ * hand_idx      dev int64 (n_hands): 1 = right hand, mirrored when mirror_right != 0
+ * forced_views  dev int32 (n_hands, max_views) or NULL: use these rig views (-1 = none) instead of the
+ *               visibility ranking
+ * Ranking: cameras that see >= min_visible of the 21 landmarks inside their image with z > 0; in index
+ * order when sort_by_index != 0 (the tracker's setting), else most landmarks first; the first
+ * max_views (<= 4) are used.
+ * Outputs, all dev: n_views int32 (n_hands); view_idx int32 (n_hands, max_views), -1 = unused slot;
+ * dst_cams float64 (n_hands, max_views, 20) in umt_warp_crops' dst_cams format; intrinsics float32
+ * (n_hands, max_views, 3, 3); extrinsics float32 (n_hands, max_views, 4, 4) = world->crop-eye with
+ * the translation in metres; status int32 (n_hands, max_views): 1 where the reference raises
+ * ValueError("Unable to create crop camera") (a point behind the crop camera or focal < 5).       */
+int umt_crop_cameras(const float* points, int n_points, const double* cameras, const double* camera_angles,
+                     int n_rig_views, const int32_t* rig_idx, const int64_t* hand_idx,
+                     const int32_t* forced_views, int n_hands, int max_views, int min_visible,
+                     int sort_by_index, int mirror_right, double focal_multiplier, int crop_w, int crop_h,
+                     int32_t* n_views, int32_t* view_idx, double* dst_cams, float* intrinsics,
+                     float* extrinsics, int32_t* status, void* stream);
+
 /* ---- A1: fisheye -> pinhole crop, _warp_image + /255, lib/tracker/tracker.py:54-80,210-211 ----
  * src_images dev uint8; image i of crop k starts at src_images + src_offset[k] with row pitch
  * src_pitch[k] (bytes) - this is how a 4-view-wide frame is addressed (video_pose_data.py:123-125).

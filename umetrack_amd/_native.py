@@ -38,6 +38,8 @@ SIGNATURES = {
     "umt_backbone_workspace_bytes": (c_int64, [c_int]),
     "umt_head_workspace_bytes": (c_int64, [c_int, c_int]),
     "umt_forward_workspace_bytes": (c_int64, [c_int, c_int]),
+    "umt_crop_cameras": (c_int, [_P, c_int, _P, _P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_double,
+                                 c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "umt_warp_crops": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "umt_resample_pinhole": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "umt_backbone_forward": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int64, _P]),

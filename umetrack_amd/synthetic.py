@@ -99,6 +99,7 @@ class Workload:
     intrinsics: np.ndarray        # [2S,3,3] float32
     extrinsics: np.ndarray        # [2S,4,4] float32 (world->crop eye, translation in metres)
     image_bytes: int              # size of the source frame buffer
+    rig_cams: np.ndarray = None   # [4,30] float64, the rig's fisheye cameras (pack_fisheye rows)
 
 
 def make_workload(n_frames: int, frames_per_recording: int, seed: int, hand_model, fk_fn) -> Workload:
@@ -136,8 +137,9 @@ def make_workload(n_frames: int, frames_per_recording: int, seed: int, hand_mode
     f, c, crop_c2w, ok = crop_cameras_batched(rig_c2w[crop_view], np.zeros(2 * S), pts2, mirror)
     if not ok.all():
         raise RuntimeError(f"{(~ok).sum()} synthetic crops are degenerate; change the seed")
-    src_cams = np.stack([gpu_warp.pack_fisheye(SRC_W, SRC_H, intr[v, :2], intr[v, 2:], coeffs[v], rig_c2w[v])
-                         for v in range(N_VIEWS)])[crop_view]
+    rig_cams = np.stack([gpu_warp.pack_fisheye(SRC_W, SRC_H, intr[v, :2], intr[v, 2:], coeffs[v], rig_c2w[v])
+                         for v in range(N_VIEWS)])
+    src_cams = rig_cams[crop_view]
     dst_cams = np.concatenate([np.stack([f, f, np.full_like(f, c), np.full_like(f, c)], 1),
                                crop_c2w.reshape(-1, 16)], axis=1)
     K = np.zeros((2 * S, 3, 3), np.float32)
@@ -151,4 +153,4 @@ def make_workload(n_frames: int, frames_per_recording: int, seed: int, hand_mode
     return Workload(n_rec=n_rec, T=T, joint_angles=ja, wrist=wrist, hand_idx=hand.astype(np.int64),
                     frame_of=frame_of.astype(np.int64), views=views, src_cams=src_cams, dst_cams=dst_cams,
                     src_offset=offs, src_pitch=np.full(2 * S, SRC_W * N_VIEWS, np.int32), intrinsics=K,
-                    extrinsics=E.astype(np.float32), image_bytes=n_frames * frame_bytes)
+                    extrinsics=E.astype(np.float32), image_bytes=n_frames * frame_bytes, rig_cams=rig_cams)
