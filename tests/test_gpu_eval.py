@@ -42,3 +42,55 @@ def test_eval_known_and_unknown_skeleton_roundtrip(tmp_path):
     path = str(tmp_path / "unknown" / "real" / "hand_hand" / "rec.npy")
     err = ev.track_sequence_unknown_skeleton(rec, model, generic, n_calibration_samples=4, output_path=path)
     assert err is not None and np.isfinite(err).all() and ev.load_result(path)["valid_tracking"].all()
+
+
+def test_eval_from_recording_on_disk(tmp_path):
+    """Label JSON + frame file -> SyncedImagePoseStream -> tracker: identical to the in-memory recording."""
+    from umetrack_amd import eval as ev
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.tracker import video_pose_data as vpd
+    hm = load_generic_hand_model()
+    rec = ev.SyntheticRecording(4, seed=42, hand_model=hm, drop_left_every=3)
+    p = str(tmp_path / "rec.mono")
+    vpd.write_recording(p, rec._frames, rec.cameras, rec.camera_angles, hm, rec.joint_angles, rec.wrist_transforms,
+                        rec.hand_confidences)
+    model = model_from_state_dict(arch.make_synthetic_state(11)).to("cuda")
+    a = ev.track_sequence(rec, model, str(tmp_path / "a.npy"))
+    b = ev.track_sequence(vpd.SyncedImagePoseStream(p), model, str(tmp_path / "b.npy"))
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)               # mm; label floats go through JSON text
+    da, db = ev.load_result(str(tmp_path / "a.npy")), ev.load_result(str(tmp_path / "b.npy"))
+    assert (da["valid_tracking"] == db["valid_tracking"]).all()
+
+
+def test_run_eval_over_a_dataset_tree(tmp_path):
+    """find_input_output_files + run_eval: test-only filter, result tree mirrors the input tree,
+    two ranks split the recordings and together cover all of them."""
+    from umetrack_amd import eval as ev
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.tracker import video_pose_data as vpd
+    hm = load_generic_hand_model()
+    root = tmp_path / "raw_data" / "real"
+    for sub, n, seed in (("userA/testing", 3, 1), ("userA/testing", 4, 2), ("userB/testing", 2, 3), ("userB/training", 2, 4)):
+        (root / sub).mkdir(parents=True, exist_ok=True)
+        rec = ev.SyntheticRecording(n, seed=seed, hand_model=hm)
+        vpd.write_recording(str(root / sub / f"rec{seed}.mono"), rec._frames, rec.cameras, rec.camera_angles, hm,
+                            rec.joint_angles, rec.wrist_transforms, rec.hand_confidences)
+    out = tmp_path / "results"
+    ins, outs = ev.find_input_output_files(str(root), str(out), test_only=True)
+    assert len(ins) == 3 and all("testing" in p for p in ins)
+    assert outs[0] == str(out / "userA" / "testing" / "rec1.npy")
+    model = model_from_state_dict(arch.make_synthetic_state(11)).to("cuda")
+    files = []
+    for rank in range(2):
+        errs, f = ev.run_eval(str(root), str(out), model, "known", rank=rank, world=2)
+        assert errs.ndim == 1 and len(f) >= 1
+        files += f
+    assert sorted(files) == sorted(outs)
+    m = ev.aggregate_metrics(str(out), verbose=False)
+    assert m.n_total == 2 * (3 + 4 + 2) and m.n_valid == m.n_total
+    errs, f = ev.run_eval(str(root), str(out / "u"), model, "unknown", generic_hand_model=hm, n_calibration_samples=2)
+    assert len(f) == 3 and np.isfinite(errs).all()
+    with pytest.raises(ValueError, match="generic hand model"):
+        ev.run_eval(str(root), str(out), model, "unknown")

@@ -183,3 +183,81 @@ def aggregate_metrics(output_dir: str, files: Optional[Sequence[str]] = None, re
         print(f"  Mean keypoint accelerations: {m.mpjpa}")
         print(f"  GT mean keypoint accelerations: {m.gt_mpjpa}")
     return m
+
+
+# ---- whole-dataset drivers: run_eval_known_skeleton.py:100-119, run_eval_unknown_skeleton.py:145-172 ----
+def find_input_output_files(input_dir: str, output_dir: str, test_only: bool,
+                            patterns: Sequence[str] = ("*.mp4", "*.mono")):
+    """run_eval_known_skeleton.py:31-45: every recording under ``input_dir`` (only folders whose path
+    contains "testing" when ``test_only``) and its result path ``output_dir/<relative path>.npy``.
+    .mono recordings (lib/tracker/video_pose_data.py) are found next to .mp4 ones."""
+    ins, outs = [], []
+    for cur, _, names in sorted(os.walk(input_dir)):
+        if test_only and "testing" not in cur:
+            continue
+        for pat in patterns:
+            for name in sorted(fnmatch.filter(names, pat)):
+                full = os.path.join(cur, name)
+                rel = os.path.relpath(full, input_dir)
+                ins.append(full)
+                outs.append(os.path.join(output_dir, os.path.splitext(rel)[0] + ".npy"))
+    logger.info("Found %d files from %s", len(ins), input_dir)
+    return ins, outs
+
+
+def run_eval(input_dir: str, output_dir: str, model, protocol: str = "known", generic_hand_model: Optional[HandModel] = None,
+             n_calibration_samples: int = 30, test_only: bool = True, rank: int = 0, world: int = 1,
+             override: bool = False):
+    """Track every recording of a dataset.  The reference fans recordings out over ``Pool(8)`` CPU
+    processes; here each rank (one per GPU, torchrun) takes whole recordings, balanced by size, and
+    ``aggregate_metrics(..., reduce_over_ranks=True)`` combines the result with one all-reduce.
+    Returns (this rank's per-frame errors concatenated, its result files)."""
+    from .lib.tracker.video_pose_data import SyncedImagePoseStream
+    if protocol not in ("known", "unknown"):
+        raise ValueError(f"protocol must be 'known' or 'unknown', got {protocol!r}")
+    if protocol == "unknown" and generic_hand_model is None:
+        raise ValueError("the unknown-skeleton protocol needs the generic hand model")
+    ins, outs = find_input_output_files(input_dir, output_dir, test_only)
+    mine = udist.shard_recordings([os.path.getsize(p) for p in ins], world)[rank]
+    errors, files = [], []
+    for i in mine:
+        stream = SyncedImagePoseStream(ins[i])
+        if protocol == "known":
+            e = track_sequence(stream, model, outs[i], override)
+        else:
+            e = track_sequence_unknown_skeleton(stream, model, generic_hand_model, n_calibration_samples, outs[i], override)
+        files.append(outs[i])
+        if e is not None:
+            errors.append(e)
+    return (np.concatenate(errors) if errors else np.zeros(0)), files
+
+
+def main():
+    import argparse
+    from .lib.common.hand import load_generic_hand_model
+    from .lib.models.model_loader import load_pretrained_model
+    ap = argparse.ArgumentParser(description="UmeTrack raw-data evaluation, one process per GPU "
+                                             "(python -m torch.distributed.run --nproc-per-node N -m umetrack_amd.eval ...)")
+    ap.add_argument("--protocol", choices=("known", "unknown"), default="known")
+    ap.add_argument("--input", required=True, help="e.g. UmeTrack_data/raw_data/real")
+    ap.add_argument("--output", required=True, help="e.g. tmp/eval_results_known_skeleton/real")
+    ap.add_argument("--weights", required=True)
+    ap.add_argument("--calibration-samples", type=int, default=30)
+    args = ap.parse_args()
+    logging.basicConfig(level=logging.INFO)
+    rank, world, local = udist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("umetrack_amd has no CPU path: an MI355X is required")
+    torch.cuda.set_device(local)
+    model = load_pretrained_model(args.weights).eval().to(torch.device("cuda", local))
+    errs, files = run_eval(args.input, args.output, model, args.protocol, load_generic_hand_model(),
+                           args.calibration_samples, rank=rank, world=world)
+    if errs.size:
+        logger.info("rank %d mean error: %s", rank, errs.mean())
+    m = aggregate_metrics(args.output, files, reduce_over_ranks=True, verbose=rank == 0)
+    if rank == 0 and m is None:
+        print("no valid frames")
+
+
+if __name__ == "__main__":
+    main()
