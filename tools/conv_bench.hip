@@ -1,6 +1,7 @@
 // Stand-alone timing harness for the convolution kernels (experiments only, not part of the library).
-//   hipcc -O3 --offload-arch=gfx950 [-DUMT_X_...=1] tools/conv_bench.hip -o /tmp/conv_bench && /tmp/conv_bench
+//   hipcc -O3 --offload-arch=gfx950 [-DUMT_X_...=1] tools/conv_bench.hip -o /tmp/conv_bench && /tmp/conv_bench [crops] [f32|bf16|both]
 #include "../umetrack_amd/csrc/conv_igemm.hip"
+#include "../umetrack_amd/csrc/conv_bf16.hip"
 #include <vector>
 #include <stdio.h>
 #include <string.h>
@@ -16,45 +17,67 @@ int set_error(int code, const char* fmt, ...) {
 
 int main(int argc, char** argv) {
   using namespace umt;
-  const int n = argc > 1 ? atoi(argv[1]) : 2048;
+  const int n = argc > 1 ? atoi(argv[1]) : 4096;
+  const char* which = argc > 2 ? argv[2] : "both";
   struct Shape { int cin, cout, hw, taps, stride, res; };
-  const Shape shapes[] = {{32, 32, 48, 9, 1, 0}, {32, 32, 48, 9, 1, 1}, {64, 64, 24, 9, 1, 0}, {128, 128, 12, 9, 1, 0},
-                          {128, 128, 12, 9, 1, 1}, {256, 256, 6, 9, 1, 0}, {64, 128, 24, 9, 2, 0}, {128, 256, 12, 1, 2, 0}};
-  for (const Shape& sh : shapes) {
-    ConvLayer L;
-    L.taps = sh.taps; L.cin = sh.cin; L.cout = sh.cout; L.cin_s = sh.cin; L.cout_s = sh.cout; L.cout_w = sh.cout;
-    L.stride = sh.stride; L.relu = 1;
-    const int ho = sh.hw / sh.stride;
-    const size_t in_n = (size_t)n * sh.hw * sh.hw * sh.cin, out_n = (size_t)n * ho * ho * sh.cout;
-    const size_t w_n = (size_t)sh.taps * sh.cin * sh.cout;
-    float *in, *out, *res, *w, *vec;
-    hipMalloc(&in, in_n * 4); hipMalloc(&out, out_n * 4); hipMalloc(&res, out_n * 4); hipMalloc(&w, w_n * 4);
-    hipMalloc(&vec, 3 * sh.cout * 4);
-    std::vector<float> h(in_n > w_n ? in_n : w_n);
-    unsigned s = 12345;
-    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
-    hipMemcpy(in, h.data(), in_n * 4, hipMemcpyHostToDevice);
-    hipMemcpy(w, h.data(), w_n * 4, hipMemcpyHostToDevice);
-    hipMemcpy(res, h.data(), (out_n < h.size() ? out_n : h.size()) * 4, hipMemcpyHostToDevice);
-    std::vector<float> v3(3 * sh.cout, 0.f);
-    for (int i = 0; i < sh.cout; ++i) v3[sh.cout + i] = 1.f;
-    hipMemcpy(vec, v3.data(), v3.size() * 4, hipMemcpyHostToDevice);
-    L.w = w; L.bias = vec; L.scale = vec + sh.cout; L.shift = vec + 2 * sh.cout;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) launch_conv(L, in, n, sh.hw, sh.hw, sh.res ? res : nullptr, out, 0);
-    hipEventRecord(e0, 0);
-    const int iters = 5;
-    for (int i = 0; i < iters; ++i) launch_conv(L, in, n, sh.hw, sh.hw, sh.res ? res : nullptr, out, 0);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    ms /= iters;
-    const double fl = 2.0 * sh.cin * sh.cout * sh.taps * ho * ho * n;
-    printf("cin %3d cout %3d hw %2d taps %d s%d res %d : %8.1f us  %6.1f TF\n", sh.cin, sh.cout, sh.hw, sh.taps, sh.stride,
-           sh.res, ms * 1e3, fl / ms / 1e9);
-    hipFree(in); hipFree(out); hipFree(res); hipFree(w); hipFree(vec);
+  const Shape shapes[] = {{32, 32, 48, 9, 1, 0}, {32, 32, 48, 9, 1, 1}, {64, 64, 24, 9, 1, 0}, {64, 64, 24, 9, 1, 1},
+                          {128, 128, 12, 9, 1, 0}, {128, 128, 12, 9, 1, 1}, {256, 256, 6, 9, 1, 0}, {256, 256, 6, 9, 1, 1},
+                          {32, 64, 48, 9, 2, 0}, {64, 128, 24, 9, 2, 0}, {128, 256, 12, 9, 2, 0}, {32, 64, 48, 1, 2, 0},
+                          {128, 256, 12, 1, 2, 0}};
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool bf = pass == 1;
+    if (!bf && !strcmp(which, "bf16")) continue;
+    if (bf && !strcmp(which, "f32")) continue;
+    const int esz = bf ? 2 : 4;
+    for (const Shape& sh : shapes) {
+      ConvLayer L;
+      L.taps = sh.taps; L.cin = sh.cin; L.cout = sh.cout; L.cin_s = sh.cin; L.cout_s = sh.cout; L.cout_w = sh.cout;
+      L.stride = sh.stride; L.relu = 1;
+      const int ho = sh.hw / sh.stride;
+      const size_t in_n = (size_t)n * sh.hw * sh.hw * sh.cin, out_n = (size_t)n * ho * ho * sh.cout;
+      const size_t w_n = (size_t)sh.taps * sh.cin * sh.cout;
+      void *in, *out, *res, *w; float* vec;
+      hipMalloc(&in, in_n * esz); hipMalloc(&out, out_n * esz); hipMalloc(&res, out_n * esz); hipMalloc(&w, w_n * esz);
+      hipMalloc(&vec, 3 * sh.cout * 4);
+      {
+        const size_t hn = in_n > w_n ? in_n : w_n;
+        std::vector<unsigned char> h(hn * esz);
+        unsigned s = 12345;
+        for (size_t i = 0; i < hn; ++i) {
+          s = s * 1664525u + 1013904223u;
+          const float v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
+          if (bf) { unsigned u; memcpy(&u, &v, 4); const unsigned short b = (unsigned short)(u >> 16); memcpy(&h[i * 2], &b, 2); }
+          else memcpy(&h[i * 4], &v, 4);
+        }
+        hipMemcpy(in, h.data(), in_n * esz, hipMemcpyHostToDevice);
+        hipMemcpy(w, h.data(), w_n * esz, hipMemcpyHostToDevice);
+        hipMemcpy(res, h.data(), (out_n < hn ? out_n : hn) * esz, hipMemcpyHostToDevice);
+      }
+      std::vector<float> v3(3 * sh.cout, 0.f);
+      for (int i = 0; i < sh.cout; ++i) v3[sh.cout + i] = 1.f;
+      hipMemcpy(vec, v3.data(), v3.size() * 4, hipMemcpyHostToDevice);
+      L.w = (const float*)w; L.wh = (const uint16_t*)w; L.bias = vec; L.scale = vec + sh.cout; L.shift = vec + 2 * sh.cout;
+      auto run = [&]() {
+        if (bf) launch_conv_bf16(L, (const uint16_t*)in, n, sh.hw, sh.hw, sh.res ? (const uint16_t*)res : nullptr, out, 0, 0);
+        else launch_conv(L, (const float*)in, n, sh.hw, sh.hw, sh.res ? (const float*)res : nullptr, (float*)out, 0);
+      };
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int i = 0; i < 2; ++i) run();
+      hipEventRecord(e0, 0);
+      const int iters = 5;
+      for (int i = 0; i < iters; ++i) run();
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms /= iters;
+      const double fl = 2.0 * sh.cin * sh.cout * sh.taps * ho * ho * n;
+      const double bytes = (double)(in_n / (sh.stride * sh.stride) + out_n * (1 + sh.res)) * esz;
+      printf("%s cin %3d cout %3d hw %2d taps %d s%d res %d : %8.1f us  %6.1f TF  %5.2f TB/s\n", bf ? "bf16" : "f32 ", sh.cin,
+             sh.cout, sh.hw, sh.taps, sh.stride, sh.res, ms * 1e3, fl / ms / 1e9, bytes / ms / 1e9);
+      hipFree(in); hipFree(out); hipFree(res); hipFree(w); hipFree(vec);
+    }
   }
   return 0;
 }

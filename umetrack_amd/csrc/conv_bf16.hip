@@ -42,9 +42,32 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 
-// accumulator tile -> LDS patch (transpose) -> rows of 4 channels per lane
-__device__ __forceinline__ void store_tile_h(const f32x16& acc, float* patch, int lane, int mbase, int cobase,
-                                             const ConvArgsH& a) {
+// Epilogue.  The residual rows of ALL the wave's tiles are requested first (one exposed memory latency per
+// workgroup instead of one per tile: the residual is the block input, long evicted from L2 when conv2
+// ends), then each accumulator tile goes through the wave's LDS patch (transpose) so that a lane owns 4
+// consecutive channels of a pixel row: conv bias -> BN scale/shift -> residual -> ReLU -> one rounding.
+template <int TM, int TN>
+__device__ __forceinline__ void load_residual_h(uint2 (&res)[TN][TM][4], int lane, int mwave, int cowave,
+                                                const ConvArgsH& a) {
+  const int q = lane & 7, rsub = lane >> 3;
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = mwave + i * 32 + 8 * k + rsub;
+        const int co = cowave + j * 32 + 4 * q;
+        const bool ok = a.residual && m < a.M && co < a.cout_s;
+        const size_t o = ok ? (size_t)m * a.cout_s + co : 0;
+        res[j][i][k] = make_uint2(0u, 0u);
+        if (ok) res[j][i][k] = *reinterpret_cast<const uint2*>(a.residual + o);
+      }
+}
+
+template <bool PRE>
+__device__ __forceinline__ void store_tile_h(const f32x16& acc, const uint2 (&res)[4], float* patch, int lane, int mbase,
+                                             int cobase, const ConvArgsH& a) {
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + li] = acc[r];
@@ -66,8 +89,8 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, float* patch, in
         v.y = (v.y + cb.y) * cs.y + ch.y;
         v.z = (v.z + cb.z) * cs.z + ch.z;
         v.w = (v.w + cb.w) * cs.w + ch.w;
-        if (a.residual) {
-          const uint2 rr = *reinterpret_cast<const uint2*>(a.residual + o);
+        if (PRE || a.residual) {
+          const uint2 rr = PRE ? res[k] : *reinterpret_cast<const uint2*>(a.residual + o);
           v.x += bf16_lo(rr.x); v.y += bf16_hi(rr.x); v.z += bf16_lo(rr.y); v.w += bf16_hi(rr.y);
         }
         if (a.relu) {
@@ -82,6 +105,20 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, float* patch, in
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+// PRE: the kernel instance is the one launched for layers WITH a residual (prefetch into registers);
+// otherwise a residual, if any, is read tile by tile.
+template <int TM, int TN, bool PRE>
+__device__ __forceinline__ void epilogue_h(const f32x16 (&acc)[TM][TN], float* patch, int lane, int mwave, int cowave,
+                                           const ConvArgsH& a) {
+  uint2 res[TN][TM][4];
+  if (PRE) load_residual_h<TM, TN>(res, lane, mwave, cowave, a);
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      store_tile_h<PRE>(acc[i][j], res[j][i], patch, lane, mwave + i * 32, cowave + j * 32, a);
 }
 
 // ------------------------------------------------------------------------------------- gather
@@ -174,15 +211,11 @@ __global__ __launch_bounds__(256) void conv_gather_bf16(ConvArgsH a) {
     }
   }
   float* patch = reinterpret_cast<float*>(smem) + wave * 32 * LDP;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      store_tile_h(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
+  epilogue_h<TM, TN, false>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
 }
 
 // ------------------------------------------------------------------------------------- halo
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
 __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -301,11 +334,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
     __syncthreads();
   }
   float* patch = reinterpret_cast<float*>(sAh) + wave * 32 * LDP;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      store_tile_h(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
+  epilogue_h<TM, TN, RES>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -322,7 +351,10 @@ static void launch_halo_h(const ConvArgsH& a, hipStream_t stream) {
   size_t lds = (size_t)(BM + 2 * a.W + 2) * LDH * 2;
   const size_t patch = (size_t)4 * 32 * LDP * sizeof(float);
   if (lds < patch) lds = patch;
-  hipLaunchKernelGGL((conv3x3s1_halo_bf16<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), lds, stream, a);
+  if (a.residual)
+    hipLaunchKernelGGL((conv3x3s1_halo_bf16<WAVES_M, WAVES_N, TM, TN, true>), grid, dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((conv3x3s1_halo_bf16<WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), lds, stream, a);
 }
 
 int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual, void* out,

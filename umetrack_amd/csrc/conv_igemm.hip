@@ -63,8 +63,12 @@ constexpr int LDA = KC + 4;   // padded A row (floats): 16 consecutive pixels hi
 // for the residual).  Instead each wave transposes the tile through its private 32x36-float LDS
 // patch and then moves whole 128-B rows with 16 bytes per lane: conv bias -> BN scale/shift ->
 // residual -> ReLU are applied on float4s.  Caller guarantees all waves are past their last LDS read.
-__device__ __forceinline__ void store_tile(const f32x16& acc, float* patch, int lane, int mbase, int cobase,
-                                           const ConvArgs& a) {
+// PRE (kernel instances launched for layers WITH a residual): the residual rows of all the wave's
+// tiles are requested before the first transpose, so a workgroup exposes one memory latency, not one
+// per tile (the residual is the block input, long evicted from L2 when conv2 ends).
+template <bool PRE>
+__device__ __forceinline__ void store_tile(const f32x16& acc, const float4 (&res)[4], float* patch, int lane, int mbase,
+                                           int cobase, const ConvArgs& a) {
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDA + li] = acc[r];
@@ -86,8 +90,8 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, float* patch, int 
         v.y = (v.y + cb.y) * cs.y + ch.y;
         v.z = (v.z + cb.z) * cs.z + ch.z;
         v.w = (v.w + cb.w) * cs.w + ch.w;
-        if (a.residual) {
-          const float4 rr = *reinterpret_cast<const float4*>(a.residual + o);
+        if (PRE || a.residual) {
+          const float4 rr = PRE ? res[k] : *reinterpret_cast<const float4*>(a.residual + o);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (a.relu) {
@@ -98,6 +102,31 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, float* patch, int 
     }
   }
   __builtin_amdgcn_wave_barrier();
+}
+
+template <int TM, int TN, bool PRE>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], float* patch, int lane, int mwave, int cowave,
+                                         const ConvArgs& a) {
+  float4 res[TN][TM][4];
+  if (PRE) {
+    const int q = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int m = mwave + i * 32 + 8 * k + rsub;
+          const int co = cowave + j * 32 + 4 * q;
+          res[j][i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < a.M && co < a.cout_s) res[j][i][k] = *reinterpret_cast<const float4*>(a.residual + (size_t)m * a.cout_s + co);
+        }
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      store_tile<PRE>(acc[i][j], res[j][i], patch, lane, mwave + i * 32, cowave + j * 32, a);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -202,11 +231,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
 
   // ---- epilogue (sA is free: every wave passed the barrier that ended the last MFMA phase) ----
   float* patch = sA + wave * 32 * LDA;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      store_tile(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
+  epilogue<TM, TN, false>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
 }
 
 
@@ -220,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
 // the activations than the gather kernel above.  Weights do not go through LDS at all: each wave
 // streams its B fragments (already packed in fragment order) from L2 into registers, one tap
 // ahead of the MFMAs that consume them.
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
 __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
@@ -361,11 +386,7 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
 
   // ---- epilogue ----
   float* patch = sA + wave * 32 * LDA;
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      store_tile(acc[i][j], patch, lane, m0 + (wm * TM + i) * 32, n0 + (wn * TN + j) * 32, a);
+  epilogue<TM, TN, RES>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -373,7 +394,10 @@ static void launch_halo(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
   const size_t lds = (size_t)(BM + 2 * a.W + 2) * LDA * sizeof(float);
-  hipLaunchKernelGGL((conv3x3s1_halo_f32<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), lds, stream, a);
+  if (a.residual)
+    hipLaunchKernelGGL((conv3x3s1_halo_f32<WAVES_M, WAVES_N, TM, TN, true>), grid, dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL((conv3x3s1_halo_f32<WAVES_M, WAVES_N, TM, TN, false>), grid, dim3(256), lds, stream, a);
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
