@@ -2,6 +2,7 @@
 //   hipcc -O3 --offload-arch=gfx950 [-DUMT_X_...=1] tools/conv_bench.hip -o /tmp/conv_bench && /tmp/conv_bench [crops] [f32|bf16|both]
 #include "../umetrack_amd/csrc/conv_igemm.hip"
 #include "../umetrack_amd/csrc/conv_bf16.hip"
+#include "../umetrack_amd/csrc/conv_thin.hip"
 #include <vector>
 #include <stdio.h>
 #include <string.h>
@@ -24,12 +25,15 @@ int main(int argc, char** argv) {
                           {128, 128, 12, 9, 1, 0}, {128, 128, 12, 9, 1, 1}, {256, 256, 6, 9, 1, 0}, {256, 256, 6, 9, 1, 1},
                           {32, 64, 48, 9, 2, 0}, {64, 128, 24, 9, 2, 0}, {128, 256, 12, 9, 2, 0}, {32, 64, 48, 1, 2, 0},
                           {128, 256, 12, 1, 2, 0}};
+  const int only = argc > 3 ? atoi(argv[3]) : -1;      // index into shapes[], -1 = all
   for (int pass = 0; pass < 2; ++pass) {
     const bool bf = pass == 1;
     if (!bf && !strcmp(which, "bf16")) continue;
     if (bf && !strcmp(which, "f32")) continue;
     const int esz = bf ? 2 : 4;
+    int shape_idx = -1;
     for (const Shape& sh : shapes) {
+      if (++shape_idx != only && only >= 0) continue;
       ConvLayer L;
       L.taps = sh.taps; L.cin = sh.cin; L.cout = sh.cout; L.cin_s = sh.cin; L.cout_s = sh.cout; L.cout_w = sh.cout;
       L.stride = sh.stride; L.relu = 1;
@@ -61,6 +65,17 @@ int main(int argc, char** argv) {
         if (bf) launch_conv_bf16(L, (const uint16_t*)in, n, sh.hw, sh.hw, sh.res ? (const uint16_t*)res : nullptr, out, 0, 0);
         else launch_conv(L, (const float*)in, n, sh.hw, sh.hw, sh.res ? (const float*)res : nullptr, (float*)out, 0);
       };
+      if (bf && (conv_thin_applicable(L, sh.hw) || g_conv_thin == 0)) {   // new kernel vs the one-tile-per-workgroup kernel
+        ConvLayer L2 = L;
+        std::vector<unsigned char> r0(out_n * esz), r1(out_n * esz);
+        g_conv_thin = 0; run(); hipDeviceSynchronize(); hipMemcpy(r0.data(), out, out_n * esz, hipMemcpyDeviceToHost);
+        hipMemset(out, 0xff, out_n * esz);
+        g_conv_thin = 1; run(); hipDeviceSynchronize(); hipMemcpy(r1.data(), out, out_n * esz, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (size_t i = 0; i < out_n * esz; ++i) bad += r0[i] != r1[i];
+        printf("  thin vs halo: %zu differing bytes of %zu\n", bad, out_n * esz);
+        if (getenv("THIN_OFF")) g_conv_thin = 0;
+      }
       hipEvent_t e0, e1;
       hipEventCreate(&e0); hipEventCreate(&e1);
       for (int i = 0; i < 2; ++i) run();

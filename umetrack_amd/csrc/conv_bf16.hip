@@ -363,6 +363,8 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
   UMT_REQUIRE(L.taps == 1 || L.taps == 9, UMT_ERR_INVALID, "conv_bf16: taps %d", L.taps);
   UMT_REQUIRE(L.cin_s % 16 == 0 && L.cout_s % 8 == 0 && L.cout_w % 32 == 0, UMT_ERR_INVALID,
               "conv_bf16: channel strides %d/%d/%d", L.cin_s, L.cout_s, L.cout_w);
+  if (!out_f32 && conv_thin_applicable(L, w))
+    return launch_conv_thin_bf16(L, in, n, h, w, residual, reinterpret_cast<uint16_t*>(out), stream);
   ConvArgsH a;
   a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
   a.residual = residual; a.out = out; a.out_f32 = out_f32;

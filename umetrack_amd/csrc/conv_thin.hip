@@ -1,0 +1,285 @@
+// Persistent bf16 kernel for the 32 -> 32 channel stride-1 3x3 convolutions of the first backbone stage
+// (lib/models/backbone_resnet.py:56-72 with planes = 32: conv1/conv2 of the two stage-1 BasicBlocks) in
+// UMT_PREC_BF16 mode.
+//
+// These layers have K = 9 * 32 only: 18 MFMAs per 32x32 output tile against 4 KB read and 2-4 KB
+// written, so they are bound by memory and by per-tile latencies, not by the matrix pipe.  With one
+// workgroup per 128-pixel tile (conv3x3s1_halo_bf16) they ran at 2.2-2.9 TB/s.  Here
+//   * the whole weight tensor lives in REGISTERS for the lifetime of the wave (18 uint4 per lane hold
+//     the packed B fragments of all 9 taps), so the tap loop issues no global loads;
+//   * one persistent workgroup of 8 waves per CU = two groups of 4 waves, one wave of each group per
+//     SIMD, working on alternate 256-pixel tiles half a tile out of phase: between two workgroup
+//     barriers one group runs the MFMAs of its tile while the other runs the epilogue of its previous
+//     tile and writes the halo range of its next one into LDS, then they swap;
+//   * the halo range of a group's tile j+1 and the residual rows of tile j are requested into registers
+//     before the MFMAs of tile j, so the memory latency is hidden inside the wave;
+//   * tiles are dealt so that each XCD works on one contiguous run of pixel rows (halo rows shared by
+//     neighbouring tiles are fetched into one L2 only).
+// Arithmetic (k order: tap, 16-channel group) is identical to conv3x3s1_halo_bf16: results are bit-identical
+// to that kernel's (tools/conv_bench.hip checks it).  The fp32 layers of the same shape stay on
+// conv3x3s1_halo_f32: with 36 float4 of weights per lane the persistent form spills or loses its
+// prefetch registers, and measured 7 % faster without and 3 % slower with a residual.
+#include "umt_internal.h"
+#include <stdlib.h>
+
+namespace umt {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ThinArgs {
+  const void* in;        // rows [M][32] (fp32 or bf16)
+  const void* w;         // packed weights (fp32 [9][4][2][32][4] or bf16 [9][2][2][32][8])
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const void* residual;  // rows [M][32] or null
+  void* out;             // rows [M][32]
+  int H, W, M, relu;
+  int ntiles;
+};
+
+constexpr int T_LDH = 40;   // bf16 per bf16 LDS row (80 B)
+constexpr int T_LDP = 36;   // floats per row of the epilogue patch
+
+// tiles of this workgroup: XCD x gets the contiguous run [x*tpx, (x+1)*tpx) and its workgroups
+// (blockIdx % 8 == x, the round-robin deal) stride through it together
+__device__ __forceinline__ void tile_walk(int ntiles, int& first, int& step, int& end) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  first = xcd * tpx + slot;
+  step = nslots;
+  end = min((xcd + 1) * tpx, ntiles);
+}
+
+__device__ __forceinline__ unsigned border_mask(int m, int M, int H, int W) {
+  unsigned mk = 0;
+  if (m < M) {
+    const int rem = m % (H * W);
+    const int y = rem / W, x = rem - y * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << (ky * 3 + kx);
+      }
+  }
+  return mk;
+}
+
+// Tiles of one 4-wave group: every other tile of the workgroup's walk.
+struct GroupWalk {
+  int first, step, count;     // tiles first + j*step, j < count, belong to this wave's group
+};
+__device__ __forceinline__ GroupWalk group_walk(int ntiles, int group) {
+  int t, tstep, tend;
+  tile_walk(ntiles, t, tstep, tend);
+  const int n = t < tend ? (tend - t + tstep - 1) / tstep : 0;     // tiles of the workgroup
+  GroupWalk g;
+  g.first = t + group * tstep;
+  g.step = 2 * tstep;
+  g.count = (n + 1 - group) >> 1;
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------ bf16
+__device__ __forceinline__ unsigned thin_pack_bf16x2(float x, float y) {
+  const __bf16 p = (__bf16)x, r = (__bf16)y;
+  return (unsigned)__builtin_bit_cast(unsigned short, p) | ((unsigned)__builtin_bit_cast(unsigned short, r) << 16);
+}
+
+template <int TM, bool RES>
+__global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
+  constexpr int BM = 128 * TM;
+  constexpr int NLD = ((BM + 2 * 48 + 2) * 4 + 255) / 256;   // uint4 slots per thread for one halo range
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_h[];
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, group = threadIdx.x >> 8;
+  const int a_bytes = (rows * T_LDH * 2 + 15) & ~15;
+  unsigned char* sA = smem_h + group * (a_bytes + 4 * 32 * T_LDP * 4);
+  float* patch = reinterpret_cast<float*>(sA + a_bytes) + wave * 32 * T_LDP;
+  const int li = lane & 31, lh = lane >> 5;
+  const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+  const uint16_t* resid = reinterpret_cast<const uint16_t*>(a.residual);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out);
+
+  uint4 breg[9][2];
+  {
+    const uint16_t* wp = reinterpret_cast<const uint16_t*>(a.w);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        breg[tap][c] = *reinterpret_cast<const uint4*>(wp + ((size_t)((tap * 2 + c) * 2 + lh) * 32 + li) * 8);
+  }
+  const int q = lane & 7, rsub = lane >> 3;
+  const float4 cb = *reinterpret_cast<const float4*>(a.bias + 4 * q);
+  const float4 cs = *reinterpret_cast<const float4*>(a.scale + 4 * q);
+  const float4 ch = *reinterpret_cast<const float4*>(a.shift + 4 * q);
+
+  const GroupWalk gw = group_walk(a.ntiles, group);
+  const GroupWalk g0 = group_walk(a.ntiles, 0);
+  const int nphase = 2 * g0.count + 1;
+
+  uint4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int tile) {
+    const int gbase = tile * BM - W - 1;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 2, qq = idx & 3;
+      const int g = gbase + r;
+      const bool ok = r < rows && g >= 0 && g < a.M;
+      const size_t off = ok ? (size_t)g * 32 + 8 * qq : 0;
+      areg[k] = *reinterpret_cast<const uint4*>(in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto write_a = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      uint4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+      if ((idx >> 2) < rows) *reinterpret_cast<uint4*>(sA + ((idx >> 2) * T_LDH + 8 * (idx & 3)) * 2) = v;
+    }
+  };
+
+  if (gw.count > 0) {
+    load_a(gw.first);
+    write_a();
+  }
+  __syncthreads();
+
+  f32x16 acc[TM];
+  uint2 res[TM][4];
+  for (int ph = 0; ph < nphase; ++ph) {
+    const int j = (ph - group) >> 1;
+    const bool mfma_phase = ((ph - group) & 1) == 0;
+    if (ph >= group && j < gw.count) {
+      const int t = gw.first + j * gw.step;
+      const int mw = t * BM + wave * TM * 32;
+      if (mfma_phase) {
+        if (j + 1 < gw.count) load_a(t + gw.step);
+        if (RES) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int m = mw + i * 32 + 8 * k + rsub;
+              const size_t off = m < a.M ? (size_t)m * 32 + 4 * q : 0;
+              res[i][k] = *reinterpret_cast<const uint2*>(resid + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned mask[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) mask[i] = border_mask(mw + i * 32 + li, a.M, H, W);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int shift = (tap / 3) * W + (tap % 3);
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              uint4 raw = *reinterpret_cast<const uint4*>(sA + (((wave * TM + i) * 32 + li + shift) * T_LDH + c * 16 + 8 * lh) * 2);
+              if (!((mask[i] >> tap) & 1u)) raw = make_uint4(0, 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, raw),
+                                                               __builtin_bit_cast(bf16x8, breg[tap][c]), acc[i], 0, 0, 0);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][r];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int row = 8 * k + rsub;
+            const int m = mw + i * 32 + row;
+            float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 4 * q);
+            v.x = (v.x + cb.x) * cs.x + ch.x;
+            v.y = (v.y + cb.y) * cs.y + ch.y;
+            v.z = (v.z + cb.z) * cs.z + ch.z;
+            v.w = (v.w + cb.w) * cs.w + ch.w;
+            if (RES) {
+              const uint2 rr = res[i][k];
+              v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+              v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+            }
+            if (a.relu) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (m < a.M)
+              *reinterpret_cast<uint2*>(out + (size_t)m * 32 + 4 * q) =
+                  make_uint2(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w));
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (j + 1 < gw.count) write_a();
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------- launch
+static int cu_count() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
+int g_conv_thin = -1;      // -1: decide from the environment once; 0 / 1: forced (tools/conv_bench.hip)
+
+bool conv_thin_applicable(const ConvLayer& L, int w) {
+  if (g_conv_thin < 0) g_conv_thin = getenv("UMT_CONV_NOTHIN") ? 0 : 1;     // A/B switch for profiling
+  return g_conv_thin && L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48;
+}
+
+static int grid_for(int ntiles, int per_cu) {
+  int g = cu_count() * per_cu;
+  g -= g % 8;
+  const int need = (ntiles + 7) / 8 * 8;        // at least one slot per XCD run
+  return g < need ? g : need;
+}
+
+#ifndef UMT_THIN_TM
+#define UMT_THIN_TM 2
+#endif
+
+int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual,
+                          uint16_t* out, hipStream_t stream) {
+  constexpr int TM = UMT_THIN_TM;
+  const int64_t M = (int64_t)n * h * w;
+  UMT_REQUIRE(L.wh, UMT_ERR_STATE, "conv_thin: layer has no bf16 weights");
+  UMT_REQUIRE(M > 0 && M < ((int64_t)1 << 31) - 4096, UMT_ERR_INVALID, "conv_thin: %lld pixels", (long long)M);
+  ThinArgs a;
+  a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift; a.residual = residual; a.out = out;
+  a.H = h; a.W = w; a.M = (int)M; a.relu = L.relu;
+  a.ntiles = (int)((M + 128 * TM - 1) / (128 * TM));
+  const size_t lds = 2 * ((((size_t)(128 * TM + 2 * w + 2) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
+  const dim3 grid(grid_for(a.ntiles, 1));
+  auto kern = residual ? conv3x3_thin32_bf16<TM, true> : conv3x3_thin32_bf16<TM, false>;
+  UMT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace umt
