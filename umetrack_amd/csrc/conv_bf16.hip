@@ -11,6 +11,10 @@
 // reported separately from the fp32 parity mode (tests/test_gpu_bf16.py states the tolerance).
 #include "umt_internal.h"
 
+#ifndef UMT_CFG64H
+#define UMT_CFG64H 2, 2, 2, 1
+#endif
+
 namespace umt {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -233,24 +237,25 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
   const int c16_total = a.cin_s >> 4;
   const int nchunks = (a.cin_s + KCH - 1) / KCH;
 
-  unsigned mask[TM];
+  // Zero padding at image borders: a tap whose neighbour does not exist reads the all-zero LDS row
+  // `rows`; the choice is made once per tile on the address, so the tap loop applies no mask.
+  int arow[TM][9];        // byte offset of the lane's operand row per tap
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wm * TM + i) * 32 + li;
-    unsigned mk = 0;
-    if (m < a.M) {
-      const int rem = m % (H * W);
-      const int y = rem / W, x = rem - y * W;
+    const bool live = m < a.M;
+    const int rem = (live ? m : 0) % (H * W);
+    const int y = rem / W, x = rem - y * W;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
-          if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << (ky * 3 + kx);
-        }
-    }
-    mask[i] = mk;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        arow[i][ky * 3 + kx] = ((ok ? (wm * TM + i) * 32 + li + ky * W + kx : rows) * LDH + 8 * lh) * 2;
+      }
   }
+  if (tid < LDH * 2 / 16) *reinterpret_cast<uint4*>(sAh + rows * LDH * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -310,16 +315,12 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
       else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
       if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
       __builtin_amdgcn_sched_barrier(0);
-      const int shift = (tap / 3) * W + (tap % 3);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         bf16x8 av[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          uint4 raw = *reinterpret_cast<const uint4*>(sAh + (((wm * TM + i) * 32 + li + shift) * LDH + c * 16 + 8 * lh) * 2);
-          if (!((mask[i] >> tap) & 1u)) raw = make_uint4(0, 0, 0, 0);
-          av[i] = __builtin_bit_cast(bf16x8, raw);
-        }
+        for (int i = 0; i < TM; ++i)
+          av[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sAh + arow[i][tap] + c * 32));
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -348,7 +349,7 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_halo_h(const ConvArgsH& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
-  size_t lds = (size_t)(BM + 2 * a.W + 2) * LDH * 2;
+  size_t lds = (size_t)(BM + 2 * a.W + 2 + 1) * LDH * 2;      // + the all-zero row
   const size_t patch = (size_t)4 * 32 * LDP * sizeof(float);
   if (lds < patch) lds = patch;
   if (a.residual)
@@ -380,7 +381,7 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
   const bool halo = L.taps == 9 && L.stride == 1 && w <= 48;
   if (L.cout_w % 128 == 0) halo ? launch_halo_h<2, 2, 2, 2>(a, stream) : launch_gather_h<2, 2, 2, 2>(a, stream);
   else if (L.cout_w == 96) halo ? launch_halo_h<4, 1, 1, 3>(a, stream) : launch_gather_h<4, 1, 1, 3>(a, stream);
-  else if (L.cout_w == 64) halo ? launch_halo_h<2, 2, 2, 1>(a, stream) : launch_gather_h<2, 2, 2, 1>(a, stream);
+  else if (L.cout_w == 64) halo ? launch_halo_h<UMT_CFG64H>(a, stream) : launch_gather_h<2, 2, 2, 1>(a, stream);
   else if (L.cout_w == 32) halo ? launch_halo_h<4, 1, 1, 1>(a, stream) : launch_gather_h<4, 1, 1, 1>(a, stream);
   else return set_error(UMT_ERR_INVALID, "conv_bf16: unsupported padded cout %d", L.cout_w);
   UMT_CHECK_HIP(hipGetLastError());

@@ -17,9 +17,6 @@
 #include <stdlib.h>
 
 // experiment switches for tools/conv_bench.hip (all off in the library build)
-#ifndef UMT_X_NOMASK
-#define UMT_X_NOMASK 0
-#endif
 #ifndef UMT_CFG64
 #define UMT_CFG64 2, 2, 2, 1
 #endif
@@ -246,11 +243,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
 // streams its B fragments (already packed in fragment order) from L2 into registers, one tap
 // ahead of the MFMAs that consume them.
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
-__global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
+__global__ __launch_bounds__(256, (TM * TN == 3 ? 1 : 2)) void conv3x3s1_halo_f32(ConvArgs a) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");
-  extern __shared__ __attribute__((aligned(16))) float sA[];   // (BM + 2W + 2) rows x LDA
+  extern __shared__ __attribute__((aligned(16))) float sA[];   // (BM + 2W + 2) rows x LDA + one zero row
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -267,25 +264,26 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
   const int c8_total = a.cin_s >> 3;
   const int nchunks = (a.cin_s + KC - 1) / KC;
 
-  // border masks: bit (ky*3+kx) set when the neighbour exists
-  unsigned mask[TM];
+  // Zero padding at image borders: tap (ky,kx) of a pixel whose neighbour does not exist reads the
+  // all-zero LDS row `rows` instead of a shifted row.  The choice is made once per tile, on the
+  // address, so the tap loop applies no mask to the operands (no VALU between ds_read and MFMA).
+  int arow[TM][9];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wm * TM + i) * 32 + li;
-    unsigned mk = 0;
-    if (m < a.M) {
-      const int rem = m % (H * W);
-      const int y = rem / W, x = rem - y * W;
+    const bool live = m < a.M;
+    const int rem = (live ? m : 0) % (H * W);
+    const int y = rem / W, x = rem - y * W;
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int yy = y + ky - 1, xx = x + kx - 1;
-          if (yy >= 0 && yy < H && xx >= 0 && xx < W) mk |= 1u << (ky * 3 + kx);
-        }
-    }
-    mask[i] = mk;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        arow[i][ky * 3 + kx] = (ok ? (wm * TM + i) * 32 + li + ky * W + kx : rows) * LDA + 4 * lh;
+      }
   }
+  if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + rows * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -357,15 +355,11 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_f32(ConvArgs a) {
       }
       if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of this tap's MFMAs
-      const int shift = (tap / 3) * W + (tap % 3);   // (ky-1)*W + (kx-1) + (W+1)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float4 av[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          av[i] = *reinterpret_cast<const float4*>(sA + ((wm * TM + i) * 32 + li + shift) * LDA + c * 8 + 4 * lh);
-          if (!UMT_X_NOMASK && !((mask[i] >> tap) & 1u)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(sA + arow[i][tap] + c * 8);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -393,7 +387,7 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_halo(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
   dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
-  const size_t lds = (size_t)(BM + 2 * a.W + 2) * LDA * sizeof(float);
+  const size_t lds = (size_t)(BM + 2 * a.W + 2 + 1) * LDA * sizeof(float);     // + the all-zero row
   if (a.residual)
     hipLaunchKernelGGL((conv3x3s1_halo_f32<WAVES_M, WAVES_N, TM, TN, true>), grid, dim3(256), lds, stream, a);
   else

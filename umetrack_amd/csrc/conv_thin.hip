@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
   const int W = a.W, H = a.H;
   const int rows = BM + 2 * W + 2;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, group = threadIdx.x >> 8;
-  const int a_bytes = (rows * T_LDH * 2 + 15) & ~15;
+  const int a_bytes = ((rows + 1) * T_LDH * 2 + 15) & ~15;      // halo range + the all-zero row
   unsigned char* sA = smem_h + group * (a_bytes + 4 * 32 * T_LDP * 4);
   float* patch = reinterpret_cast<float*>(sA + a_bytes) + wave * 32 * T_LDP;
   const int li = lane & 31, lh = lane >> 5;
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
     }
   };
 
+  if (tid < T_LDH * 2 / 16) *reinterpret_cast<uint4*>(sA + rows * T_LDH * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
   if (gw.count > 0) {
     load_a(gw.first);
     write_a();
@@ -176,22 +177,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-        unsigned mask[TM];
+        int arow[TM][9];      // byte offset of the lane's operand row per tap; the zero row where padded
 #pragma unroll
-        for (int i = 0; i < TM; ++i) mask[i] = border_mask(mw + i * 32 + li, a.M, H, W);
+        for (int i = 0; i < TM; ++i) {
+          const unsigned mk = border_mask(mw + i * 32 + li, a.M, H, W);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+            arow[i][tap] = ((((mk >> tap) & 1u) ? (wave * TM + i) * 32 + li + (tap / 3) * W + (tap % 3) : rows) * T_LDH + 8 * lh) * 2;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int shift = (tap / 3) * W + (tap % 3);
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-              uint4 raw = *reinterpret_cast<const uint4*>(sA + (((wave * TM + i) * 32 + li + shift) * T_LDH + c * 16 + 8 * lh) * 2);
-              if (!((mask[i] >> tap) & 1u)) raw = make_uint4(0, 0, 0, 0);
+              const uint4 raw = *reinterpret_cast<const uint4*>(sA + arow[i][tap] + c * 32);
               acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, raw),
                                                                __builtin_bit_cast(bf16x8, breg[tap][c]), acc[i], 0, 0, 0);
             }
@@ -273,7 +277,7 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
   a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift; a.residual = residual; a.out = out;
   a.H = h; a.W = w; a.M = (int)M; a.relu = L.relu;
   a.ntiles = (int)((M + 128 * TM - 1) / (128 * TM));
-  const size_t lds = 2 * ((((size_t)(128 * TM + 2 * w + 2) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
+  const size_t lds = 2 * ((((size_t)(128 * TM + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
   const dim3 grid(grid_for(a.ntiles, 1));
   auto kern = residual ? conv3x3_thin32_bf16<TM, true> : conv3x3_thin32_bf16<TM, false>;
   UMT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
