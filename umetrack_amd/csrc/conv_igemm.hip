@@ -20,6 +20,14 @@
 #ifndef UMT_CFG64
 #define UMT_CFG64 2, 2, 2, 1
 #endif
+// padded cout 96 (fusion 108->72, temporal 90, regressor 76): three 32-wide cout tiles in grid.y rather than
+// one 96-wide workgroup tile - 3x the workgroups for the 6x6 maps and 158 instead of 280 registers
+#ifndef UMT_CFG96
+#define UMT_CFG96 4, 1, 1, 1
+#endif
+#ifndef UMT_CFG96G
+#define UMT_CFG96G 4, 1, 1, 1
+#endif
 #ifndef UMT_CFG32
 #define UMT_CFG32 4, 1, 1, 1
 #endif
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
 // streams its B fragments (already packed in fragment order) from L2 into registers, one tap
 // ahead of the MFMAs that consume them.
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
-__global__ __launch_bounds__(256, (TM * TN == 3 ? 1 : 2)) void conv3x3s1_halo_f32(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3s1_halo_f32(ConvArgs a) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");
@@ -424,7 +432,7 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   static const bool force_gather = getenv("UMT_CONV_GATHER") != nullptr;   // A/B switch for profiling
   if (L.taps == 9 && L.stride == 1 && w <= 48 && !force_gather) {
     if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
-    else if (L.cout_w == 96) launch_halo<4, 1, 1, 3>(a, stream);
+    else if (L.cout_w == 96) launch_halo<UMT_CFG96>(a, stream);
     else if (L.cout_w == 64) launch_halo<UMT_CFG64>(a, stream);
     else if (L.cout_w == 32) launch_halo<UMT_CFG32>(a, stream);
     else return set_error(UMT_ERR_INVALID, "conv: unsupported padded cout %d", L.cout_w);
@@ -432,7 +440,7 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
     return 0;
   }
   if (L.cout_w % 128 == 0) launch_cfg<2, 2, 2, 2>(a, stream);
-  else if (L.cout_w == 96) launch_cfg<4, 1, 1, 3>(a, stream);
+  else if (L.cout_w == 96) launch_cfg<UMT_CFG96G>(a, stream);
   else if (L.cout_w == 64) launch_cfg<2, 2, 2, 1>(a, stream);
   else if (L.cout_w == 32) launch_cfg<4, 1, 1, 1>(a, stream);
   else return set_error(UMT_ERR_INVALID, "conv: unsupported padded cout %d", L.cout_w);
