@@ -42,7 +42,7 @@ enum {
 
 enum { UMT_PREC_FP32 = 0, UMT_PREC_BF16 = 1 };
 enum { UMT_HEAD_KNOWN_SKELETON = 0, UMT_HEAD_PREDICT_SCALE = 1 };
-enum { UMT_WARP_CV2_FIXED_POINT = 0, UMT_WARP_FLOAT = 1 };
+enum { UMT_WARP_CV2_FIXED_POINT = 0, UMT_WARP_FLOAT = 1, UMT_WARP_CV2_FIXED_POINT_F64 = 2 };
 
 const char* umt_last_error(void);
 int umt_abi_version(void);

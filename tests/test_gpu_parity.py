@@ -267,3 +267,40 @@ def test_metric_partials_match_reference_golden():
     # and against the reference's float64 numbers (inputs rounded to float32 on the way in)
     assert abs(fin.mpjpe - float(g["mpjpe"])) < 1e-4 and round(fin.mpjpe, 2) == round(float(g["mpjpe"]), 2)
     assert round(fin.mpjpa, 2) == round(float(g["mpjpa"]), 2)
+
+
+def test_warp_fast_maps_bit_identical_to_float64_maps():
+    """MODE_CV2 evaluates the camera model in float32 and re-evaluates in float64 only the pixels whose
+    1/32-px rounding the float32 error could change; it must reproduce the all-float64 mode bit for bit.
+    Checked on the reference's golden cameras (incl. the behind-the-camera case) and on 4096 synthetic
+    rig/crop camera pairs of the bench workload with perturbed distortion (37.7 M pixels)."""
+    from umetrack_amd import synthetic
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.common.hand_skinning import skin_landmarks
+    from umetrack_amd.lib.tracker import warp as w
+    # (1) golden cameras
+    g = load_npz("warp_maps.npz")
+    rng = np.random.default_rng(5)
+    for i in range(int(g["n_cases"])):
+        W, H, s, d = _pack_case(g, i)
+        img = torch.from_numpy(rng.integers(0, 256, size=(H * W + 16,), dtype=np.uint8))
+        a = w.warp_crops(img, [0], [W], s[None], d[None], mode=w.MODE_CV2)
+        b = w.warp_crops(img, [0], [W], s[None], d[None], mode=w.MODE_CV2_F64)
+        assert torch.equal(a, b), (i, int((a != b).sum()))
+    # (2) bench-style cameras, stronger distortion, random source offsets
+    hm = load_generic_hand_model()
+
+    def fk(ja, wr, hidx):
+        return skin_landmarks(hm, torch.from_numpy(ja), torch.from_numpy(wr), hand_idx=torch.from_numpy(hidx),
+                              mirror_right=True).cpu().numpy()
+    wl = synthetic.make_workload(1024, 64, 17, hm, fk)
+    src = wl.src_cams.copy()
+    src[:, 6:14] *= rng.uniform(0.0, 8.0, size=(src.shape[0], 1))          # k1..k6, p1, p2 up to 8x the bench's
+    dev = torch.device("cuda")
+    images = torch.randint(0, 256, (wl.image_bytes,), dtype=torch.uint8, device=dev)
+    args = (images, torch.from_numpy(wl.src_offset).to(dev), torch.from_numpy(wl.src_pitch).to(dev),
+            torch.from_numpy(src).to(dev), torch.from_numpy(wl.dst_cams).to(dev))
+    a = w.warp_crops(*args, mode=w.MODE_CV2)
+    b = w.warp_crops(*args, mode=w.MODE_CV2_F64)
+    assert a.shape[0] == 4096
+    assert torch.equal(a, b), int((a != b).sum())

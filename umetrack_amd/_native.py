@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
 
 PREC_FP32, PREC_BF16 = 0, 1
 HEAD_KNOWN_SKELETON, HEAD_PREDICT_SCALE = 0, 1
-WARP_CV2_FIXED_POINT, WARP_FLOAT = 0, 1
+WARP_CV2_FIXED_POINT, WARP_FLOAT, WARP_CV2_FIXED_POINT_F64 = 0, 1, 2
 METRIC_WORDS = 108
 
 _ERR_NAMES = {1: "invalid argument", 2: "bad state", 3: "state_dict key", 4: "HIP runtime",

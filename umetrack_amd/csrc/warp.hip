@@ -6,19 +6,30 @@
 //  * umt_resample_pinhole - pinhole -> pinhole float bilinear, replaces _resample_images_batched
 //                         (lib/batched_dataset/data_transform.py:78-144).
 //
-// One workgroup per crop.  Pass 1 evaluates the coordinate map in double precision (the
-// reference builds it with float64 numpy and casts to float32) and keeps the 36 fixed-point
+// One workgroup per crop.  Pass 1 evaluates the coordinate map and keeps the 20 fixed-point
 // coordinates per thread in registers while the workgroup reduces their bounding box.  Pass 2
 // copies that source rectangle into LDS with coalesced row reads, pass 3 gathers the four taps
 // from LDS and writes whole 384-B output rows.  Rectangles that do not fit fall back to
 // gathering from global memory.  Algorithmic traffic: 4 source bytes + 4 output bytes per pixel.
+//
+// The reference builds the map with float64 numpy and casts it to float32; OpenCV then rounds the
+// coordinate to 1/32 px.  In UMT_WARP_CV2_FIXED_POINT mode only that integer matters, so pass 1 runs
+// the camera model in float32 first (same formulas on a pre-multiplied rotation) and accepts the
+// result where the 1/32-px rounding cannot be affected by the float32 error (bound WARP_FAST_ULPS
+// relative roundings, 6x the largest error seen on the test and bench cameras).  The other pixels
+// (a few per cent: within the bound of a rounding boundary, near z = 0, not finite) are queued in
+// LDS and re-evaluated in float64 by the whole workgroup, densely.  UMT_WARP_CV2_FIXED_POINT_F64
+// evaluates every pixel in float64 (the tests hold the two modes bit-identical); UMT_WARP_FLOAT
+// always uses float64 maps.
 #include "umt_internal.h"
 
 namespace umt {
 
-constexpr int WARP_THREADS = 256;
-constexpr int WARP_MAX_PX = 36;                 // 96*96 / 256
+constexpr int WARP_THREADS = 512;                // 8 waves per crop, 2 crops per CU: 4 waves per SIMD hide the maps' dependent chains
+constexpr int WARP_MAX_PX = 20;                 // >= 96*96 / 512, as 5 groups of 4 consecutive pixels
 constexpr int WARP_LDS_BYTES = 60 * 1024;       // source rectangle budget (2 workgroups per CU)
+constexpr int WARP_QCAP = 3072;                 // float64 re-evaluation queue (aliases the rectangle: 30 KB)
+constexpr float WARP_FAST_ULPS = 12.0f;         // accepted float32 error of a source coordinate, in 2^-23 * |coordinate|
 
 struct SrcCam {
   double w, h, fx, fy, cx, cy, k1, k2, k3, k4, p1, p2, k5, k6, xf[16];
@@ -26,6 +37,85 @@ struct SrcCam {
 struct DstCam {
   double fx, fy, cx, cy, xf[16];
 };
+
+// float32 camera constants of one crop for the fast map
+struct FastCam {
+  float m[9], t[3];          // source-eye = m * crop-eye + t
+  float ifx, ify, dcx, dcy;  // crop camera
+  float fx, fy, cx, cy, k1, k2, k3, k4, k5, k6, p1, p2;
+};
+
+__device__ inline FastCam make_fast(const SrcCam& s, const DstCam& d) {
+  FastCam f;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c)
+      f.m[r * 3 + c] = (float)(s.xf[0 + r] * d.xf[0 + c] + s.xf[4 + r] * d.xf[4 + c] + s.xf[8 + r] * d.xf[8 + c]);
+    f.t[r] = (float)(s.xf[0 + r] * (d.xf[3] - s.xf[3]) + s.xf[4 + r] * (d.xf[7] - s.xf[7]) + s.xf[8 + r] * (d.xf[11] - s.xf[11]));
+  }
+  f.ifx = (float)(1.0 / d.fx); f.ify = (float)(1.0 / d.fy); f.dcx = (float)d.cx; f.dcy = (float)d.cy;
+  f.fx = (float)s.fx; f.fy = (float)s.fy; f.cx = (float)s.cx; f.cy = (float)s.cy;
+  f.k1 = (float)s.k1; f.k2 = (float)s.k2; f.k3 = (float)s.k3; f.k4 = (float)s.k4; f.k5 = (float)s.k5; f.k6 = (float)s.k6;
+  f.p1 = (float)s.p1; f.p2 = (float)s.p2;
+  return f;
+}
+
+// float32 map of one pixel -> 1/32-px integers.  Returns false when the float64 evaluation must decide.
+// Uses the hardware reciprocal / reciprocal-square-root / square-root (1 ulp each) and a degree-9
+// polynomial in a^2 for atan(a)/a on [0,1] (6e-8 relative in float32); all of it is inside the error
+// bound that decides whether the float32 result is accepted.
+__device__ inline bool map_point_fast(const FastCam& f, int u, int v, int& sx, int& sy) {
+  const float qx = ((float)u - f.dcx) * f.ifx, qy = ((float)v - f.dcy) * f.ify;
+  const float inv = __builtin_amdgcn_rsqf(qx * qx + qy * qy + 1.0f);
+  const float ex = qx * inv, ey = qy * inv, ez = inv;
+  const float x = f.m[0] * ex + f.m[1] * ey + f.m[2] * ez + f.t[0];
+  const float y = f.m[3] * ex + f.m[4] * ey + f.m[5] * ez + f.t[1];
+  const float z = f.m[6] * ex + f.m[7] * ey + f.m[8] * ez + f.t[2];
+  // depth check (tracker.py:71-73): the sign of z must be certain
+  const float zmag = fabsf(x) + fabsf(y) + fabsf(z);
+  if (!(fabsf(z) > 1e-4f * zmag)) return false;
+  if (z < 0.f) { sx = -32; sy = -32; return true; }
+  // sc = atan2(r, z) / r with z > 0: a = min/max, theta = a*P(a^2) or pi/2 - a*P(a^2)
+  const float r = __builtin_amdgcn_sqrtf(x * x + y * y);
+  const float inv_hi = __builtin_amdgcn_rcpf(fmaxf(r, z));
+  const float a = fminf(r, z) * inv_hi, s2 = a * a;
+  const float P = 1.0f + s2 * (-0.3333328366279602f + s2 * (0.1999826580286026f + s2 * (-0.142619326710701f + s2 * (0.1094203069806099f +
+                  s2 * (-0.08377315104007721f + s2 * (0.05755209922790527f + s2 * (-0.030804594978690147f + s2 * (0.01072694268077612f +
+                  s2 * -0.0017539297696202993f))))))));
+  const float sc = (r <= z ? P : 1.5707963267948966f - a * P) * inv_hi;
+  const float px = x * sc, py = y * sc;
+  const float r2 = fminf(px * px + py * py, 9.8696044f);
+  const float radial = 1.0f + r2 * (f.k1 + r2 * (f.k2 + r2 * (f.k3 + r2 * (f.k4 + r2 * (f.k5 + r2 * f.k6)))));
+  // relative sensitivity of the radial factor to r2: g / |radial| with g = r2 * |radial'|.  Where the
+  // distortion polynomial is steep (far off axis) the float32 error is amplified: leave it to float64.
+  const float dradial = f.k1 + r2 * (2.f * f.k2 + r2 * (3.f * f.k3 + r2 * (4.f * f.k4 + r2 * (5.f * f.k5 + r2 * 6.f * f.k6))));
+  const float g = r2 * fabsf(dradial), arad = fabsf(radial);
+  if (!(g <= 0.5f * arad)) return false;
+  const float ux = px * radial, uy = py * radial;
+  const float x2 = ux * ux, y2 = uy * uy, xy = ux * uy, rr = x2 + y2;
+  const float tx = 2.0f * f.p2 * xy + f.p1 * (rr + 2.0f * x2), ty = 2.0f * f.p1 * xy + f.p2 * (rr + 2.0f * y2);
+  const float dx = ux + tx, dy = uy + ty;
+  const float ox = dx * f.fx + f.cx, oy = dy * f.fy + f.cy;
+  if (!(fabsf(ox) < 30000.f && fabsf(oy) < 30000.f)) return false;          // also catches NaN
+  const float cx32 = ox * 32.0f, cy32 = oy * 32.0f;
+  const float rx = rintf(cx32), ry = rintf(cy32);
+  // distance to the nearest rounding boundary (k + 0.5) must exceed the error bound, in 1/32 px:
+  //   bound = 32 * (ULPS+1) * 2^-23 * (1 + 4 g/|radial|) * magnitude, magnitude = the largest value that
+  //   entered the coordinate; compared after multiplying through by |radial|
+  const float kb = 32.0f * (WARP_FAST_ULPS + 1.0f) * 1.1920929e-7f * (arad + 4.0f * g);
+  const float magx = fmaxf((fabsf(ux) + fabsf(tx)) * fabsf(f.fx) + fabsf(f.cx), 64.f);
+  const float magy = fmaxf((fabsf(uy) + fabsf(ty)) * fabsf(f.fy) + fabsf(f.cy), 64.f);
+  if (!((0.5f - fabsf(cx32 - rx)) * arad > kb * magx && (0.5f - fabsf(cy32 - ry)) * arad > kb * magy)) return false;
+  sx = (int)rx; sy = (int)ry;
+  return true;
+}
+
+__device__ inline void quantise_map(float mx, float my, int& sx, int& sy) {
+  const float cx = fminf(fmaxf(mx * 32.0f, -1048576.f), 1048576.f);   // NaN -> lower bound
+  const float cy = fminf(fmaxf(my * 32.0f, -1048576.f), 1048576.f);
+  sx = (int)rintf(cx);
+  sy = (int)rintf(cy);
+}
+
 
 // window (u,v) of the crop camera -> window coordinates in the fisheye source, as float32
 __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v, float& mx, float& my) {
@@ -61,11 +151,15 @@ __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v,
   my = (float)oy;
 }
 
+// pixel handled by slot i of thread tid: groups of 4 consecutive pixels, groups dealt round-robin to the threads
+__device__ __forceinline__ int warp_pixel(int tid, int i) { return 4 * (tid + (i >> 2) * WARP_THREADS) + (i & 3); }
+
 template <bool FROM_LDS>
 __device__ inline int fetch(const uint8_t* img, int pitch, int W, int H, const uint8_t* tile, int tx0, int ty0,
                             int tpitch, int y, int x) {
   if (x < 0 || y < 0 || x >= W || y >= H) return 0;   // BORDER_CONSTANT 0
-  if (FROM_LDS) return tile[(y - ty0) * tpitch + (x - tx0)];
+  if (FROM_LDS)    // LDS row = the source row from the 4-byte-aligned address at or below its first rectangle byte
+    return tile[(y - ty0) * tpitch + (x - tx0) + (int)((reinterpret_cast<uintptr_t>(img) + (size_t)y * pitch + tx0) & 3)];
   return img[(size_t)y * pitch + x];
 }
 
@@ -95,56 +189,141 @@ __device__ inline float sample(int mode, const uint8_t* img, int pitch, int W, i
   return v / 255.0f;
 }
 
-__global__ __launch_bounds__(WARP_THREADS) void warp_kernel(const uint8_t* __restrict__ src_images,
+// The float64 camera pair of crop k.  Loaded where it is used (uniform, scalar-cached loads): holding its
+// 50 doubles across the float32 pass would cost ~100 registers.
+__device__ inline void load_cams(const double* __restrict__ src_cams, const double* __restrict__ dst_cams, int k, SrcCam& s,
+                                 DstCam& d) {
+  const double* sp = src_cams + (size_t)k * 30;
+  s.w = sp[0]; s.h = sp[1]; s.fx = sp[2]; s.fy = sp[3]; s.cx = sp[4]; s.cy = sp[5];
+  s.k1 = sp[6]; s.k2 = sp[7]; s.k3 = sp[8]; s.k4 = sp[9]; s.p1 = sp[10]; s.p2 = sp[11]; s.k5 = sp[12]; s.k6 = sp[13];
+  for (int i = 0; i < 16; ++i) s.xf[i] = sp[14 + i];
+  const double* dp = dst_cams + (size_t)k * 20;
+  d.fx = dp[0]; d.fy = dp[1]; d.cx = dp[2]; d.cy = dp[3];
+  for (int i = 0; i < 16; ++i) d.xf[i] = dp[4 + i];
+}
+
+// MODE: UMT_WARP_CV2_FIXED_POINT (float32 map + float64 re-evaluation queue), UMT_WARP_FLOAT,
+// UMT_WARP_CV2_FIXED_POINT_F64 (every pixel in float64)
+template <int MODE>
+__global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __restrict__ src_images,
                                                             const int64_t* __restrict__ src_offset,
                                                             const int32_t* __restrict__ src_pitch,
                                                             const double* __restrict__ src_cams,
                                                             const double* __restrict__ dst_cams, int out_h, int out_w,
-                                                            int mode, float* __restrict__ out) {
+                                                            float* __restrict__ out) {
+  constexpr bool CV2 = MODE != UMT_WARP_FLOAT;
+  constexpr int smode = CV2 ? UMT_WARP_CV2_FIXED_POINT : UMT_WARP_FLOAT;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ int red[4][WARP_THREADS / 64];
+  __shared__ int qcount;
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
-  SrcCam s;
-  DstCam d;
-  {
-    const double* sp = src_cams + (size_t)k * 30;
-    s.w = sp[0]; s.h = sp[1]; s.fx = sp[2]; s.fy = sp[3]; s.cx = sp[4]; s.cy = sp[5];
-    s.k1 = sp[6]; s.k2 = sp[7]; s.k3 = sp[8]; s.k4 = sp[9]; s.p1 = sp[10]; s.p2 = sp[11]; s.k5 = sp[12]; s.k6 = sp[13];
-    for (int i = 0; i < 16; ++i) s.xf[i] = sp[14 + i];
-    const double* dp = dst_cams + (size_t)k * 20;
-    d.fx = dp[0]; d.fy = dp[1]; d.cx = dp[2]; d.cy = dp[3];
-    for (int i = 0; i < 16; ++i) d.xf[i] = dp[4 + i];
-  }
-  const int W = (int)s.w, H = (int)s.h;
+  const int W = (int)src_cams[(size_t)k * 30], H = (int)src_cams[(size_t)k * 30 + 1];
   const int pitch = src_pitch[k];
   const uint8_t* img = src_images + src_offset[k];
   const int npx = out_h * out_w;
 
   int sxs[WARP_MAX_PX], sys[WARP_MAX_PX];
-  float mxs[WARP_MAX_PX], mys[WARP_MAX_PX];
+  float mxs[CV2 ? 1 : WARP_MAX_PX], mys[CV2 ? 1 : WARP_MAX_PX];
+
+  if (MODE == UMT_WARP_CV2_FIXED_POINT) {
+    // float32 map; pixels it cannot decide go to the queue: pixel ids, then their float64 results
+    uint16_t* qpix = reinterpret_cast<uint16_t*>(lds);
+    int* qres = reinterpret_cast<int*>(lds + WARP_QCAP * 2);
+    if (tid == 0) qcount = 0;
+    __syncthreads();
+    FastCam f;
+    {
+      SrcCam s;
+      DstCam d;
+      load_cams(src_cams, dst_cams, k, s, d);
+      f = make_fast(s, d);
+    }
+    unsigned queued = 0;
+    int gu = 0, gv = 0;
+#pragma unroll
+    for (int i = 0; i < WARP_MAX_PX; ++i) {
+      const int p = warp_pixel(tid, i);
+      sxs[i] = sys[i] = -32;
+      bool undecided = false;
+      if (p < npx) {
+        if ((i & 3) == 0) { gv = p / out_w; gu = p - gv * out_w; }      // one division per group of 4 pixels
+        int u = gu + (i & 3), v = gv;
+        if (u >= out_w) { u -= out_w; ++v; }
+        undecided = !map_point_fast(f, u, v, sxs[i], sys[i]);
+      }
+      if (undecided) {
+        const int pos = atomicAdd(&qcount, 1);
+        if (pos < WARP_QCAP) qpix[pos] = (uint16_t)p;
+        sxs[i] = pos;
+        queued |= 1u << i;
+      }
+    }
+    __syncthreads();
+    const int nq = qcount;
+    SrcCam s;
+    DstCam d;
+    if (nq > 0) load_cams(src_cams, dst_cams, k, s, d);
+    if (nq <= WARP_QCAP) {
+      for (int q = tid; q < nq; q += WARP_THREADS) {
+        const int p = qpix[q];
+        const int v = p / out_w, u = p - v * out_w;
+        float mx, my;
+        map_point(s, d, u, v, mx, my);
+        int sx, sy;
+        quantise_map(mx, my, sx, sy);
+        qres[2 * q] = sx;
+        qres[2 * q + 1] = sy;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < WARP_MAX_PX; ++i)
+        if ((queued >> i) & 1u) {
+          const int pos = sxs[i];
+          sxs[i] = qres[2 * pos];
+          sys[i] = qres[2 * pos + 1];
+        }
+    } else {          // degenerate crop: every thread re-evaluates its own undecided pixels
+#pragma unroll
+      for (int i = 0; i < WARP_MAX_PX; ++i)
+        if ((queued >> i) & 1u) {
+          const int p = warp_pixel(tid, i);
+          const int v = p / out_w, u = p - v * out_w;
+          float mx, my;
+          map_point(s, d, u, v, mx, my);
+          quantise_map(mx, my, sxs[i], sys[i]);
+        }
+    }
+  } else {
+    SrcCam s;
+    DstCam d;
+    load_cams(src_cams, dst_cams, k, s, d);
+#pragma unroll
+    for (int i = 0; i < WARP_MAX_PX; ++i) {
+      const int p = warp_pixel(tid, i);
+      sxs[i] = sys[i] = -32;
+      if (!CV2) mxs[i] = mys[i] = -1.f;
+      if (p < npx) {
+        const int v = p / out_w, u = p - v * out_w;
+        float mx, my;
+        map_point(s, d, u, v, mx, my);
+        if (CV2) {
+          quantise_map(mx, my, sxs[i], sys[i]);
+        } else {
+          mxs[i] = mx; mys[i] = my;
+          sxs[i] = (int)fmin(fmax(floor((double)mx), -4.0), 1.0e6);     // integer sample position
+          sys[i] = (int)fmin(fmax(floor((double)my), -4.0), 1.0e6);
+        }
+      }
+    }
+  }
+
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = -(1 << 30), by1 = -(1 << 30);
 #pragma unroll
   for (int i = 0; i < WARP_MAX_PX; ++i) {
-    const int p = tid + i * WARP_THREADS;
-    sxs[i] = sys[i] = -32;
-    mxs[i] = mys[i] = -1.f;
+    const int p = warp_pixel(tid, i);
     if (p < npx) {
-      const int v = p / out_w, u = p - v * out_w;
-      float mx, my;
-      map_point(s, d, u, v, mx, my);
-      mxs[i] = mx; mys[i] = my;
-      int ix, iy;
-      if (mode == UMT_WARP_CV2_FIXED_POINT) {
-        const float cx = fminf(fmaxf(mx * 32.0f, -1048576.f), 1048576.f);   // NaN -> lower bound
-        const float cy = fminf(fmaxf(my * 32.0f, -1048576.f), 1048576.f);
-        sxs[i] = (int)rintf(cx);
-        sys[i] = (int)rintf(cy);
-        ix = sxs[i] >> 5; iy = sys[i] >> 5;
-      } else {
-        ix = (int)fmin(fmax(floor((double)mx), -4.0), 1.0e6);
-        iy = (int)fmin(fmax(floor((double)my), -4.0), 1.0e6);
-      }
+      const int ix = CV2 ? sxs[i] >> 5 : sxs[i], iy = CV2 ? sys[i] >> 5 : sys[i];
       if (ix + 1 >= 0 && ix < W && iy + 1 >= 0 && iy < H) {   // footprint touches the image
         bx0 = min(bx0, ix); bx1 = max(bx1, ix + 1);
         by0 = min(by0, iy); by1 = max(by1, iy + 1);
@@ -159,37 +338,58 @@ __global__ __launch_bounds__(WARP_THREADS) void warp_kernel(const uint8_t* __res
   if ((tid & 63) == 0) {
     red[0][tid >> 6] = bx0; red[1][tid >> 6] = by0; red[2][tid >> 6] = bx1; red[3][tid >> 6] = by1;
   }
-  __syncthreads();
-  bx0 = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
-  by0 = min(min(red[1][0], red[1][1]), min(red[1][2], red[1][3]));
-  bx1 = max(max(red[2][0], red[2][1]), max(red[2][2], red[2][3]));
-  by1 = max(max(red[3][0], red[3][1]), max(red[3][2], red[3][3]));
+  __syncthreads();          // also: every read of the re-evaluation queue is done before the rectangle overwrites it
+  bx0 = red[0][0]; by0 = red[1][0]; bx1 = red[2][0]; by1 = red[3][0];
+#pragma unroll
+  for (int wv = 1; wv < WARP_THREADS / 64; ++wv) {
+    bx0 = min(bx0, red[0][wv]); by0 = min(by0, red[1][wv]);
+    bx1 = max(bx1, red[2][wv]); by1 = max(by1, red[3][wv]);
+  }
   bx0 = max(bx0, 0); by0 = max(by0, 0);
   bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
   const bool empty = bx1 < bx0 || by1 < by0;
   const int tw = empty ? 0 : bx1 - bx0 + 1, th = empty ? 0 : by1 - by0 + 1;
-  const int tpitch = (tw + 3) & ~3;
+  const int tpitch = ((tw + 3) & ~3) + 4;          // bytes per LDS row: rectangle width + alignment slack, dword multiple
   const bool use_lds = !empty && (int64_t)tpitch * th <= WARP_LDS_BYTES;   // uniform over the workgroup
 
+  float res[WARP_MAX_PX];
   if (use_lds) {
-    for (int row = tid >> 6; row < th; row += WARP_THREADS / 64) {
-      const uint8_t* srow = img + (size_t)(by0 + row) * pitch + bx0;
-      uint8_t* drow = lds + row * tpitch;
-      for (int x = tid & 63; x < tw; x += 64) drow[x] = srow[x];
+    // aligned 4-byte copies: LDS row r holds the dwords that cover source bytes [bx0, bx0 + tw) of row by0 + r
+    const int tpd = tpitch >> 2;
+    const int total = tpd * th;
+    uint32_t* lds32 = reinterpret_cast<uint32_t*>(lds);
+#pragma unroll 4
+    for (int idx = tid; idx < total; idx += WARP_THREADS) {
+      const int row = idx / tpd, col = idx - row * tpd;
+      const uintptr_t a0 = (reinterpret_cast<uintptr_t>(img) + (size_t)(by0 + row) * pitch + bx0) & ~(uintptr_t)3;
+      const int mis = (int)((reinterpret_cast<uintptr_t>(img) + (size_t)(by0 + row) * pitch + bx0) & 3);
+      uint32_t v = 0;
+      if (4 * col < mis + tw) v = *reinterpret_cast<const uint32_t*>(a0 + 4 * (size_t)col);
+      lds32[idx] = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < WARP_MAX_PX; ++i) {
-      const int p = tid + i * WARP_THREADS;
-      if (p < npx)
-        out[(size_t)k * npx + p] = sample<true>(mode, img, pitch, W, H, lds, bx0, by0, tpitch, sxs[i], sys[i], mxs[i], mys[i]);
-    }
+    for (int i = 0; i < WARP_MAX_PX; ++i)
+      res[i] = sample<true>(smode, img, pitch, W, H, lds, bx0, by0, tpitch, sxs[i], sys[i], CV2 ? 0.f : mxs[i],
+                            CV2 ? 0.f : mys[i]);
   } else {
 #pragma unroll
-    for (int i = 0; i < WARP_MAX_PX; ++i) {
-      const int p = tid + i * WARP_THREADS;
-      if (p < npx)
-        out[(size_t)k * npx + p] = sample<false>(mode, img, pitch, W, H, lds, 0, 0, 0, sxs[i], sys[i], mxs[i], mys[i]);
+    for (int i = 0; i < WARP_MAX_PX; ++i)
+      res[i] = warp_pixel(tid, i) < npx
+                   ? sample<false>(smode, img, pitch, W, H, lds, 0, 0, 0, sxs[i], sys[i], CV2 ? 0.f : mxs[i], CV2 ? 0.f : mys[i])
+                   : 0.f;
+  }
+  float* obase = out + (size_t)k * npx;
+  const bool vec = (npx & 3) == 0;               // then every group of 4 is whole and 16-byte aligned
+#pragma unroll
+  for (int gq = 0; gq < WARP_MAX_PX / 4; ++gq) {
+    const int p = warp_pixel(tid, 4 * gq);
+    if (vec) {
+      if (p < npx) *reinterpret_cast<float4*>(obase + p) = make_float4(res[4 * gq], res[4 * gq + 1], res[4 * gq + 2], res[4 * gq + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (p + j < npx) obase[p + j] = res[4 * gq + j];
     }
   }
 }
@@ -226,13 +426,17 @@ extern "C" int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offs
                               float* out, void* stream) {
   using namespace umt;
   if (n == 0) return 0;
-  UMT_REQUIRE(n > 0 && out_h > 0 && out_w > 0, UMT_ERR_INVALID, "warp: n=%d out=%dx%d", n, out_h, out_w);
+  UMT_REQUIRE(n > 0 && out_h > 0 && out_w >= 4, UMT_ERR_INVALID, "warp: n=%d out=%dx%d (width must be >= 4)", n, out_h, out_w);
   UMT_REQUIRE(out_h * out_w <= WARP_MAX_PX * WARP_THREADS, UMT_ERR_UNSUPPORTED,
               "warp: crops larger than %d pixels are not supported (got %dx%d)", WARP_MAX_PX * WARP_THREADS, out_w, out_h);
-  UMT_REQUIRE(mode == UMT_WARP_CV2_FIXED_POINT || mode == UMT_WARP_FLOAT, UMT_ERR_INVALID, "warp: mode %d", mode);
+  UMT_REQUIRE(mode == UMT_WARP_CV2_FIXED_POINT || mode == UMT_WARP_FLOAT || mode == UMT_WARP_CV2_FIXED_POINT_F64,
+              UMT_ERR_INVALID, "warp: mode %d", mode);
   UMT_REQUIRE(src_images && src_offset && src_pitch && src_cams && dst_cams && out, UMT_ERR_INVALID, "warp: null pointer");
-  hipLaunchKernelGGL(warp_kernel, dim3(n), dim3(WARP_THREADS), WARP_LDS_BYTES, (hipStream_t)stream, src_images,
-                     src_offset, src_pitch, src_cams, dst_cams, out_h, out_w, mode, out);
+  auto kern = mode == UMT_WARP_CV2_FIXED_POINT ? warp_kernel<UMT_WARP_CV2_FIXED_POINT>
+              : mode == UMT_WARP_FLOAT         ? warp_kernel<UMT_WARP_FLOAT>
+                                               : warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64>;
+  hipLaunchKernelGGL(kern, dim3(n), dim3(WARP_THREADS), WARP_LDS_BYTES, (hipStream_t)stream, src_images, src_offset,
+                     src_pitch, src_cams, dst_cams, out_h, out_w, out);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
