@@ -30,7 +30,12 @@ def models(golden_sequence):
     _, seed = golden_sequence
     state = arch.make_synthetic_state(seed)
     gm = model_from_state_dict(state).to("cuda")
+    gm._umt_test_seed = seed
     return gm, state
+
+
+def gm_seed(models):
+    return models[0]._umt_test_seed
 
 
 @pytest.mark.parametrize("n", [1, 5, 16])
@@ -94,3 +99,33 @@ def test_bf16_end_to_end_cost_on_golden_sequence(models, golden_sequence):
     assert worst_t < WRIST_TOL_M
     assert worst_a < ANGLE_TOL_RAD
     gm.reset_memory()
+
+
+def test_bf16_persistent_thin_kernel_bit_identical_to_halo_kernel(models, tmp_path):
+    """The 32-channel stage runs on the persistent kernel of conv_thin.hip; with UMT_CONV_NOTHIN=1 (read once
+    per process, hence the child process) it runs on conv3x3s1_halo_bf16.  Same arithmetic order, so the
+    backbone features must agree bit for bit, also for a crop count that leaves the last 256-pixel tile ragged."""
+    import os
+    import subprocess
+    import sys
+    gm, _ = models
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "halo.npy"
+    child = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from umetrack_amd import arch\n"
+        "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
+        f"gm = model_from_state_dict(arch.make_synthetic_state({int(gm_seed(models))})).to('cuda')\n"
+        "gm.precision = 'bf16'\n"
+        "img = torch.rand(7, 96, 96, generator=torch.Generator().manual_seed(31))\n"
+        f"np.save({str(out)!r}, gm.backbone(img.cuda()).cpu().numpy())\n")
+    env = dict(os.environ, UMT_CONV_NOTHIN="1")
+    subprocess.run([sys.executable, "-c", child], check=True, env=env, timeout=110)
+    img = torch.rand(7, 96, 96, generator=torch.Generator().manual_seed(31))
+    gm.precision = "bf16"
+    try:
+        got = gm.backbone(img.cuda()).cpu().numpy()
+    finally:
+        gm.precision = "fp32"
+    assert np.array_equal(got, np.load(out))

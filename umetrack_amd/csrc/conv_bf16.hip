@@ -269,7 +269,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
   const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 8);
   const size_t w_c16 = (size_t)2 * a.cout_w * 16;       // bytes per 16-channel group
   const size_t w_tap = (size_t)c16_total * w_c16;
-  uint4 bcur[2][TN], bnext[2][TN];
+  // ring of three tap slots (9 taps per chunk, so the slot of a tap is static): the fragments of tap t+2
+  // are requested while tap t runs - two taps are only 8-16 MFMAs, about one L2 round trip
+  uint4 bring[3][2][TN];
   auto load_b = [&](uint4 (&dst)[2][TN], int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -279,7 +281,8 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
       for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const uint4*>(wu + j * 512 + wlane_off);
     }
   };
-  load_b(bcur, 0, 0);
+  load_b(bring[0], 0, 0);
+  load_b(bring[1], 1, 0);
 
   constexpr int NLD = ((BM + 2 * 48 + 2) * 4 + 255) / 256;
   uint4 areg[NLD];
@@ -311,8 +314,8 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
     __syncthreads();
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (tap < 8) load_b(bnext, tap + 1, chunk);
-      else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
+      if (tap < 7) load_b(bring[(tap + 2) % 3], tap + 2, chunk);
+      else if (chunk + 1 < nchunks) load_b(bring[(tap + 2) % 3], tap - 7, chunk + 1);
       if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -325,12 +328,8 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bcur[c][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bring[tap % 3][c][j]), acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bcur[c][j] = bnext[c][j];
     }
     __syncthreads();
   }
