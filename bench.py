@@ -41,6 +41,42 @@ BACKBONE_FLOP_PER_CROP = 969.23e6      # 484.61 MMAC per
 MODEL_FLOP_PER_HAND = 1.958e9          # 2 views, known-skeleton head
 FP32_MATRIX_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MATRIX_PEAK_TFLOPS = 2516.6       # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E peak (about 6.3 TB/s is achievable)
+
+
+def backbone_activation_bytes_per_crop(esz):
+    """Algorithmic HBM bytes of the UNFUSED backbone per crop: input + output (+ residual) rows of each of its
+    28 launches, activations of `esz` bytes (4 = fp32 rows, 2 = bf16 rows); weights (17 MB per call) left out."""
+    rd, wr = 96 * 96 * 4, 48 * 48 * 32 * esz                      # stem: fp32 crop in, pooled rows out
+    hw = 48
+    for cin, cout, st, nb in [(32, 32, 1, 2), (32, 64, 2, 3), (64, 128, 2, 5), (128, 256, 2, 2)]:
+        for blk in range(nb):
+            ci, s = (cin, st) if blk == 0 else (cout, 1)
+            ho = hw // s
+            rd += hw * hw * ci * esz                               # conv1
+            wr += ho * ho * cout * esz
+            if blk == 0 and st != 1:                               # 1x1 stride-2 down-sample branch
+                rd += ho * ho * ci * esz
+                wr += ho * ho * cout * esz
+            rd += 2 * ho * ho * cout * esz                         # conv2 reads conv1's output and the residual
+            wr += ho * ho * cout * esz
+            hw = ho
+    rd += 36 * 256 * esz                                           # projection, fp32 feature rows out
+    wr += 36 * 72 * 4
+    return rd + wr
+
+
+def h2d_rate_gbs(device, nbytes=1 << 30):
+    """Pinned host -> device copy rate (GB/s), for the PCIe-inclusive figure; not part of the timed region."""
+    host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    devb = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    devb.copy_(host, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        devb.copy_(host, non_blocking=True)
+    torch.cuda.synchronize()
+    return 3 * nbytes / (time.perf_counter() - t0) / 1e9
 
 
 class Pipeline:
@@ -187,6 +223,7 @@ def main():
                     help="backbone arithmetic; fp32 is the reference's and the headline line, bf16 is a separate mode")
     ap.add_argument("--host-crop-cameras", action="store_true",
                     help="use crop cameras precomputed on the host instead of generating them on the GPU each step")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host->device copy-rate measurement")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: all ranks share cuda:0 (use with --backend gloo on a 1-GPU box)")
@@ -246,17 +283,19 @@ def main():
     if rank != 0:
         return
     crops_per_call = 2 * pipe.chunk
+    bf16 = args.precision == "bf16"
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_backbone_traffic.json")
     if os.path.exists(tpath):      # PMC passes cannot run inside this process; see the file for provenance
         with open(tpath) as fh:
             tj = json.load(fh)
-        traffic = (tj["read_bytes_per_crop"] + tj["write_bytes_per_crop"]) * crops_per_call
+        tj = tj.get(args.precision, tj if not bf16 else {})
+        if "read_bytes_per_crop" in tj:
+            traffic = (tj["read_bytes_per_crop"] + tj["write_bytes_per_crop"]) * crops_per_call
     achieved = BACKBONE_FLOP_PER_CROP * crops_per_call / (bb_ms / calls * 1e-3) / 1e12
-    bf16 = args.precision == "bf16"
     peak = BF16_MATRIX_PEAK_TFLOPS if bf16 else FP32_MATRIX_PEAK_TFLOPS
-    if bf16:
-        traffic = None       # the PMC passes on file were taken in fp32 mode
+    act_bytes = backbone_activation_bytes_per_crop(2 if bf16 else 4) * crops_per_call
+    hbm_achieved = act_bytes / (bb_ms / calls * 1e-3) / 1e9
     line = {
         "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -271,6 +310,10 @@ def main():
                      "frac": achieved / peak, "traffic": traffic,
                      "traffic_note": "HBM bytes per forward call from rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
                                      "profiles/r01_backbone_traffic.json (measured at 2048 crops/call, scaled per crop)",
+                     "hbm_view": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": hbm_achieved / HBM_PEAK_GBS,
+                                  "note": "same launches priced by bytes: unfused input+output(+residual) rows of every "
+                                          "backbone launch; the bf16 backbone sits between the two rooflines"},
                      "kernel": "backbone: stem + 27 " + ("conv_*_bf16" if bf16 else "conv_igemm_f32 / conv3x3s1_halo_f32")
                                + " launches per forward call",
                      "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
@@ -281,6 +324,14 @@ def main():
                       "note": f"{pipe.wl.n_rec} recordings x {pipe.wl.T} frames in lock-step, use_memory=True after "
                               "frame 0, rank 0 only, 1 timed pass", "mpjpe_mm": rec_fin.mpjpe},
     }
+    if not args.no_pcie:
+        rate = h2d_rate_gbs(dev)
+        frame_bytes = pipe.wl.image_bytes
+        t_step = elapsed / args.steps
+        line["pcie_inclusive"] = {"value": pipe.S / (t_step + frame_bytes / (rate * 1e9)), "unit": "hand-frames/s per GPU",
+                                  "h2d_GBs": rate, "frame_bytes_per_step": frame_bytes,
+                                  "note": "step time plus an un-overlapped pinned host->device copy of the step's source "
+                                          "frames at the measured rate; `value` above has the frames resident in HBM"}
     if args.cpu_hands > 0:
         base, cpu_pred, cpu_mpjpe = cpu_baseline(pipe, args.cpu_hands)
         line["cpu_baseline"] = base
