@@ -6,6 +6,7 @@
 #include <vector>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 namespace umt {
 static thread_local char g_err2[512];
@@ -92,6 +93,54 @@ int main(int argc, char** argv) {
       printf("%s cin %3d cout %3d hw %2d taps %d s%d res %d : %8.1f us  %6.1f TF  %5.2f TB/s\n", bf ? "bf16" : "f32 ", sh.cin,
              sh.cout, sh.hw, sh.taps, sh.stride, sh.res, ms * 1e3, fl / ms / 1e9, bytes / ms / 1e9);
       hipFree(in); hipFree(out); hipFree(res); hipFree(w); hipFree(vec);
+    }
+  }
+  // fused stride-2 conv1 + down-sample vs the two separate launches
+  if (strcmp(which, "bf16")) {
+    const int cfgs[3][3] = {{32, 64, 48}, {64, 128, 24}, {128, 256, 12}};
+    for (auto& cf : cfgs) {
+      const int cin = cf[0], cout = cf[1], hw = cf[2], ho = hw / 2;
+      ConvLayer C, D;
+      C.taps = 9; C.cin = cin; C.cout = cout; C.cin_s = cin; C.cout_s = cout; C.cout_w = cout; C.stride = 2; C.relu = 1;
+      D = C; D.taps = 1; D.relu = 0;
+      const size_t in_n = (size_t)n * hw * hw * cin, out_n = (size_t)n * ho * ho * cout, w_n = (size_t)9 * cin * cout;
+      float *in, *o1, *o2, *d1, *d2, *w, *wd, *vec;
+      hipMalloc(&in, in_n * 4); hipMalloc(&o1, out_n * 4); hipMalloc(&o2, out_n * 4); hipMalloc(&d1, out_n * 4); hipMalloc(&d2, out_n * 4);
+      hipMalloc(&w, w_n * 4); hipMalloc(&wd, w_n * 4); hipMalloc(&vec, 3 * cout * 4);
+      std::vector<float> h(in_n > w_n ? in_n : w_n);
+      unsigned s = 777;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+      hipMemcpy(in, h.data(), in_n * 4, hipMemcpyHostToDevice);
+      hipMemcpy(w, h.data(), w_n * 4, hipMemcpyHostToDevice);
+      hipMemcpy(wd, h.data() + 1000, (size_t)cin * cout * 4, hipMemcpyHostToDevice);
+      std::vector<float> v3(3 * cout, 0.f);
+      for (int i = 0; i < cout; ++i) { v3[i] = 0.01f * (i % 7); v3[cout + i] = 1.f + 0.01f * (i % 5); v3[2 * cout + i] = -0.02f * (i % 3); }
+      hipMemcpy(vec, v3.data(), v3.size() * 4, hipMemcpyHostToDevice);
+      C.w = w; D.w = wd; C.bias = D.bias = vec; C.scale = D.scale = vec + cout; C.shift = D.shift = vec + 2 * cout;
+      launch_conv(C, in, n, hw, hw, nullptr, o1, 0);
+      launch_conv(D, in, n, hw, hw, nullptr, d1, 0);
+      hipMemset(o2, 0xff, out_n * 4); hipMemset(d2, 0xff, out_n * 4);
+      if (launch_conv_s2_fused(C, &D, in, n, hw, hw, o2, d2, 0)) return 1;
+      hipDeviceSynchronize();
+      std::vector<float> a(out_n), b(out_n);
+      hipMemcpy(a.data(), o1, out_n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o2, out_n * 4, hipMemcpyDeviceToHost);
+      double e1 = 0, mx = 0;
+      for (size_t i = 0; i < out_n; ++i) { e1 = fmax(e1, fabs((double)a[i] - b[i])); mx = fmax(mx, fabs((double)a[i])); }
+      hipMemcpy(a.data(), d1, out_n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), d2, out_n * 4, hipMemcpyDeviceToHost);
+      size_t bad = 0;
+      for (size_t i = 0; i < out_n; ++i) bad += memcmp(&a[i], &b[i], 4) != 0;
+      hipEvent_t e0, e1v; hipEventCreate(&e0); hipEventCreate(&e1v);
+      float ms_sep, ms_fused;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) { launch_conv(C, in, n, hw, hw, nullptr, o1, 0); launch_conv(D, in, n, hw, hw, nullptr, d1, 0); }
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_sep, e0, e1v);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) launch_conv_s2_fused(C, &D, in, n, hw, hw, o2, d2, 0);
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_fused, e0, e1v);
+      const double fl = 2.0 * cin * cout * 10 * ho * ho * n;
+      printf("s2+ds %3d->%3d hw %2d: conv1 max|diff| %.3g (max|x| %.3g), ds differing words %zu; separate %.1f us, fused %.1f us (%.1f TF)\n",
+             cin, cout, hw, e1, mx, bad, ms_sep / 5 * 1e3, ms_fused / 5 * 1e3, fl / (ms_fused / 5) / 1e9);
+      hipFree(in); hipFree(o1); hipFree(o2); hipFree(d1); hipFree(d2); hipFree(w); hipFree(wd); hipFree(vec);
     }
   }
   return 0;

@@ -337,6 +337,147 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
   epilogue_h<TM, TN, RES>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
 }
 
+// ------------------------------------------------------------------------------ stride 2 + down-sample
+// bf16 form of conv3x3s2_ds_f32 (conv_igemm.hip): conv1 (3x3, stride 2) of a stage's first block and its
+// 1x1 stride-2 down-sample branch in one kernel; the input range of a 64-pixel output tile is staged once
+// per 32-channel chunk and the centre tap feeds both accumulator sets.
+constexpr int S2H_BM = 64;
+constexpr int S2H_ROWS_MAX = 448;
+
+struct ConvS2ArgsH {
+  ConvArgsH c1;
+  const uint16_t* ds_w;
+  const float* ds_bias;
+  const float* ds_scale;
+  const float* ds_shift;
+  uint16_t* ds_out;
+};
+
+template <int TN, bool DS>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_ds_bf16(ConvS2ArgsH g) {
+  const ConvArgsH& a = g.c1;
+  constexpr int BM = S2H_BM, BN = 2 * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sAh[];   // rows x 80 B + one zero row (or the patches)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+  const int c16_total = a.cin_s >> 4;
+  const int nchunks = (a.cin_s + KCH - 1) / KCH;
+
+  auto centre = [&](int m) {
+    const int R = m / Wo, xo = m - R * Wo;
+    return 2 * W * R + 2 * xo;
+  };
+  const int m_last = min(m0 + BM, a.M) - 1;
+  const int g0 = centre(m0) - W - 1;
+  const int rows = centre(m_last) + W + 1 - g0 + 1;
+  const int zrow = S2H_ROWS_MAX;
+
+  int arow[9];
+  {
+    const int m = m0 + wm * 32 + li;
+    const bool live = m < a.M;
+    const int mm = live ? m : m0;
+    const int R = mm / Wo, xo = mm - R * Wo, yo = R % Ho;
+    const int base = 2 * W * R + 2 * xo - g0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
+        const bool ok = live && yy >= 0 && yy < a.H && xx >= 0 && xx < W;
+        arow[ky * 3 + kx] = ((ok ? base + (ky - 1) * W + (kx - 1) : zrow) * LDH + 8 * lh) * 2;
+      }
+  }
+  if (tid < LDH * 2 / 16) *reinterpret_cast<uint4*>(sAh + zrow * LDH * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
+
+  f32x16 acc[1][TN], accd[1][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][j][r] = 0.f; accd[0][j][r] = 0.f; }
+
+  const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 16);
+  const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 8);
+  const char* dblock = reinterpret_cast<const char*>(g.ds_w + (size_t)n0 * 8);
+  const size_t w_c16 = (size_t)2 * a.cout_w * 16;
+  const size_t w_tap = (size_t)c16_total * w_c16;
+  uint4 bring[3][2][TN], bds[2][TN];
+  auto load_b = [&](uint4 (&dst)[2][TN], const char* blk, int tap, int chunk) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int c16 = min(chunk * 2 + c, c16_total - 1);
+      const char* wu = blk + tap * w_tap + c16 * w_c16;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const uint4*>(wu + j * 512 + wlane_off);
+    }
+  };
+  load_b(bring[0], wblock, 0, 0);
+  load_b(bring[1], wblock, 1, 0);
+
+  constexpr int NLD = S2H_ROWS_MAX * 4 / 256;
+  uint4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * KCH;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 2, q = idx & 3;
+      const int gp = g0 + r;
+      const bool ok = r < rows && gp >= 0 && (c0 + 8 * q) < a.cin_s;
+      const size_t off = ok ? (size_t)gp * a.cin_s + c0 + 8 * q : 0;
+      areg[k] = *reinterpret_cast<const uint4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  load_a(0);
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      uint4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+      if ((idx >> 2) < rows) *reinterpret_cast<uint4*>(sAh + ((idx >> 2) * LDH + 8 * (idx & 3)) * 2) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 7) load_b(bring[(tap + 2) % 3], wblock, tap + 2, chunk);
+      else if (chunk + 1 < nchunks) load_b(bring[(tap + 2) % 3], wblock, tap - 7, chunk + 1);
+      if (DS && tap == 2) load_b(bds, dblock, 0, chunk);
+      if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sAh + arow[tap] + c * 32));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bring[tap % 3][c][j]), acc[0][j], 0, 0, 0);
+        if (DS && tap == 4) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, bds[c][j]), accd[0][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* patch = reinterpret_cast<float*>(sAh) + wave * 32 * LDP;
+  epilogue_h<1, TN, false>(acc, patch, lane, m0 + wm * 32, n0 + wn * TN * 32, a);
+  if (DS) {
+    ConvArgsH d = a;
+    d.bias = g.ds_bias; d.scale = g.ds_scale; d.shift = g.ds_shift; d.out = g.ds_out; d.relu = 0; d.residual = nullptr;
+    epilogue_h<1, TN, false>(accd, patch, lane, m0 + wm * 32, n0 + wn * TN * 32, d);
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_gather_h(const ConvArgsH& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -383,6 +524,32 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
   else if (L.cout_w == 64) halo ? launch_halo_h<UMT_CFG64H>(a, stream) : launch_gather_h<2, 2, 2, 1>(a, stream);
   else if (L.cout_w == 32) halo ? launch_halo_h<4, 1, 1, 1>(a, stream) : launch_gather_h<4, 1, 1, 1>(a, stream);
   else return set_error(UMT_ERR_INVALID, "conv_bf16: unsupported padded cout %d", L.cout_w);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_s2_fused_bf16(const ConvLayer& c1, const ConvLayer* ds, const uint16_t* in, int n, int h, int w,
+                              uint16_t* out, uint16_t* ds_out, hipStream_t stream) {
+  UMT_REQUIRE(conv_s2_fused_applicable(c1, ds, h, w) && c1.cin_s % 16 == 0, UMT_ERR_INVALID, "conv_s2_bf16: layer shapes not supported");
+  UMT_REQUIRE(c1.wh && (!ds || (ds->wh && ds_out)) && n > 0, UMT_ERR_INVALID, "conv_s2_bf16: bad arguments");
+  ConvS2ArgsH g;
+  ConvArgsH& a = g.c1;
+  a.in = in; a.w = c1.wh; a.bias = c1.bias; a.scale = c1.scale; a.shift = c1.shift; a.residual = nullptr; a.out = out;
+  a.out_f32 = 0;
+  a.H = h; a.W = w; a.Ho = h / 2; a.Wo = w / 2;
+  a.cin_s = c1.cin_s; a.cout_s = c1.cout_s; a.cout_w = c1.cout_w; a.stride = 2; a.taps = 9; a.relu = c1.relu;
+  UMT_REQUIRE((int64_t)n * h * w < ((int64_t)1 << 31) - 65536, UMT_ERR_INVALID, "conv_s2_bf16: too many pixels");
+  a.M = n * a.Ho * a.Wo;
+  g.ds_w = ds ? ds->wh : nullptr; g.ds_bias = ds ? ds->bias : nullptr; g.ds_scale = ds ? ds->scale : nullptr;
+  g.ds_shift = ds ? ds->shift : nullptr; g.ds_out = ds_out;
+  size_t lds = (size_t)(S2H_ROWS_MAX + 1) * LDH * 2;
+  const size_t patch = (size_t)4 * 32 * LDP * sizeof(float);
+  if (lds < patch) lds = patch;
+  const bool wide = c1.cout_w % 128 == 0;
+  dim3 grid((a.M + S2H_BM - 1) / S2H_BM, c1.cout_w / (wide ? 128 : 64));
+  void (*kern)(ConvS2ArgsH) = wide ? (ds ? conv3x3s2_ds_bf16<2, true> : conv3x3s2_ds_bf16<2, false>)
+                                   : (ds ? conv3x3s2_ds_bf16<1, true> : conv3x3s2_ds_bf16<1, false>);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

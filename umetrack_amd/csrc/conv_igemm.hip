@@ -391,6 +391,167 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_halo_f32(ConvArgs a) {
   epilogue<TM, TN, RES>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
 }
 
+// ---------------------------------------------------------------------------------------------
+// First block of a stage (backbone_resnet.py:56-72 with stride 2 and a down-sample branch): the
+// stride-2 3x3 conv1 and the stride-2 1x1 down-sample convolution read the same input, and the 1x1's
+// operand is exactly the centre tap of the 3x3.  One kernel computes both.  Like the stride-1 halo
+// kernel it stages, per 32-channel chunk, ONE contiguous range of input pixel rows - here the rows
+// from the first output pixel's top-left tap to the last output pixel's bottom-right tap, i.e. about
+// 4 input pixels per output pixel - and every tap reads it through a per-lane row address fixed once
+// per tile (the all-zero row where the tap falls outside the image).  The centre tap additionally
+// feeds a second set of accumulators with the down-sample weights.  Against the per-tap gather
+// kernel this stages A once instead of nine times per chunk, needs 2 instead of 18 barriers per
+// chunk, and drops the separate down-sample launch with its re-read of the input.
+constexpr int S2_BM = 64;            // output pixels per workgroup: 2 waves along pixels x 2 along cout
+constexpr int S2_ROWS_MAX = 448;     // staged input rows (host checks 2W*ceil(63/Wo) + 3W + 1 <= this)
+
+struct ConvS2Args {
+  ConvArgs c1;        // conv1: in, w, epilogue constants, out; H, W, Ho, Wo, cin_s, cout_s, cout_w, relu, M
+  const float* ds_w;  // down-sample: packed [1][cin_s/8][2][cout_w][4], or null
+  const float* ds_bias;
+  const float* ds_scale;
+  const float* ds_shift;
+  float* ds_out;
+};
+
+template <int TN, bool DS>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
+  const ConvArgs& a = g.c1;
+  constexpr int BM = S2_BM, BN = 2 * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) float sA[];   // rows x LDA + one zero row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+  const int c8_total = a.cin_s >> 3;
+  const int nchunks = (a.cin_s + KC - 1) / KC;
+
+  // centre-tap input pixel of output pixel m: 2W * (global output row) + 2 * xo
+  auto centre = [&](int m) {
+    const int R = m / Wo, xo = m - R * Wo;
+    return 2 * W * R + 2 * xo;
+  };
+  const int m_last = min(m0 + BM, a.M) - 1;
+  const int g0 = centre(m0) - W - 1;                     // global input pixel row of LDS row 0
+  const int rows = centre(m_last) + W + 1 - g0 + 1;      // <= S2_ROWS_MAX (checked on the host)
+  const int zrow = S2_ROWS_MAX;                          // the all-zero LDS row
+
+  int arow[9];
+  {
+    const int m = m0 + wm * 32 + li;
+    const bool live = m < a.M;
+    const int mm = live ? m : m0;
+    const int R = mm / Wo, xo = mm - R * Wo, yo = R % Ho;
+    const int base = 2 * W * R + 2 * xo - g0;            // LDS row of the centre tap
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
+        const bool ok = live && yy >= 0 && yy < a.H && xx >= 0 && xx < W;
+        arow[ky * 3 + kx] = (ok ? base + (ky - 1) * W + (kx - 1) : zrow) * LDA + 4 * lh;
+      }
+  }
+  if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + zrow * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  f32x16 acc[1][TN], accd[1][TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][j][r] = 0.f; accd[0][j][r] = 0.f; }
+
+  const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 4 * sizeof(float));
+  const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 4);
+  const char* dblock = reinterpret_cast<const char*>(g.ds_w + (size_t)n0 * 4);
+  const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float);
+  const size_t w_tap = (size_t)c8_total * w_c8;
+  float4 bcur[4][TN], bnext[4][TN], bds[4][TN];
+  auto load_b = [&](float4 (&dst)[4][TN], const char* blk, int tap, int chunk) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int c8 = min(chunk * 4 + c, c8_total - 1);
+      const char* wu = blk + tap * w_tap + c8 * w_c8;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const float4*>(wu + j * 512 + wlane_off);
+    }
+  };
+  load_b(bcur, wblock, 0, 0);
+
+  constexpr int NLD = S2_ROWS_MAX / 32;                  // float4 slots per thread
+  float4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * KC;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 3, q = idx & 7;
+      const int gp = g0 + r;
+      const bool ok = r < rows && gp >= 0 && (c0 + 4 * q) < a.cin_s;      // gp < n*H*W follows from r < rows
+      const size_t off = ok ? (size_t)gp * a.cin_s + c0 + 4 * q : 0;
+      areg[k] = *reinterpret_cast<const float4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  load_a(0);
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      float4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) load_b(bnext, wblock, tap + 1, chunk);
+      else if (chunk + 1 < nchunks) load_b(bnext, wblock, 0, chunk + 1);
+      if (DS && tap == 3) load_b(bds, dblock, 0, chunk);
+      if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float4 av = *reinterpret_cast<const float4*>(sA + arow[tap] + c * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bcur[c][j].x, acc[0][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bcur[c][j].y, acc[0][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bcur[c][j].z, acc[0][j], 0, 0, 0);
+          acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bcur[c][j].w, acc[0][j], 0, 0, 0);
+        }
+        if (DS && tap == 4) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bds[c][j].x, accd[0][j], 0, 0, 0);
+            accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bds[c][j].y, accd[0][j], 0, 0, 0);
+            accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bds[c][j].z, accd[0][j], 0, 0, 0);
+            accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bds[c][j].w, accd[0][j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bcur[c][j] = bnext[c][j];
+    }
+    __syncthreads();
+  }
+
+  float* patch = sA + wave * 32 * LDA;
+  epilogue<1, TN, false>(acc, patch, lane, m0 + wm * 32, n0 + wn * TN * 32, a);
+  if (DS) {
+    ConvArgs d = a;
+    d.bias = g.ds_bias; d.scale = g.ds_scale; d.shift = g.ds_shift; d.out = g.ds_out; d.relu = 0; d.residual = nullptr;
+    epilogue<1, TN, false>(accd, patch, lane, m0 + wm * 32, n0 + wn * TN * 32, d);
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_halo(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -444,6 +605,42 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   else if (L.cout_w == 64) launch_cfg<2, 2, 2, 1>(a, stream);
   else if (L.cout_w == 32) launch_cfg<4, 1, 1, 1>(a, stream);
   else return set_error(UMT_ERR_INVALID, "conv: unsupported padded cout %d", L.cout_w);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// conv1 (3x3, stride 2) of a stage's first block, fused with its down-sample 1x1 (ds may be null).
+bool conv_s2_fused_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w) {
+  static const bool off = getenv("UMT_CONV_NOS2") != nullptr;     // A/B switch for profiling
+  if (off || c1.taps != 9 || c1.stride != 2 || (h & 1) || (w & 1) || c1.cout_w % 64 != 0 || c1.cin_s % 8 != 0) return false;
+  const int wo = w / 2;
+  if (2 * w * ((S2_BM - 1 + wo - 1) / wo) + 3 * w + 1 > S2_ROWS_MAX) return false;
+  if (ds && (ds->taps != 1 || ds->stride != 2 || ds->cin_s != c1.cin_s || ds->cout_w != c1.cout_w || ds->cout_s != c1.cout_s))
+    return false;
+  return true;
+}
+
+int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* in, int n, int h, int w, float* out,
+                         float* ds_out, hipStream_t stream) {
+  UMT_REQUIRE(conv_s2_fused_applicable(c1, ds, h, w), UMT_ERR_INVALID, "conv_s2: layer shapes not supported");
+  UMT_REQUIRE(n > 0 && (!ds || ds_out), UMT_ERR_INVALID, "conv_s2: bad arguments");
+  ConvS2Args g;
+  ConvArgs& a = g.c1;
+  a.in = in; a.w = c1.w; a.bias = c1.bias; a.scale = c1.scale; a.shift = c1.shift; a.residual = nullptr; a.out = out;
+  a.H = h; a.W = w; a.Ho = h / 2; a.Wo = w / 2;
+  a.cin_s = c1.cin_s; a.cout_s = c1.cout_s; a.cout_w = c1.cout_w; a.stride = 2; a.taps = 9; a.relu = c1.relu;
+  const int64_t M = (int64_t)n * a.Ho * a.Wo;
+  UMT_REQUIRE((int64_t)n * h * w < ((int64_t)1 << 31) - 65536, UMT_ERR_INVALID, "conv_s2: too many pixels");
+  a.M = (int)M;
+  g.ds_w = ds ? ds->w : nullptr; g.ds_bias = ds ? ds->bias : nullptr; g.ds_scale = ds ? ds->scale : nullptr;
+  g.ds_shift = ds ? ds->shift : nullptr; g.ds_out = ds_out;
+  const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
+  // 64 x 64 workgroup tiles (one 32x32 tile per wave and convolution): wider cout tiles would need the
+  // weight double buffers of both convolutions for two tiles and spill
+  dim3 grid((a.M + S2_BM - 1) / S2_BM, c1.cout_w / 64);
+  void (*kern)(ConvS2Args) = ds ? conv3x3s2_ds_f32<1, true> : conv3x3s2_ds_f32<1, false>;
+  UMT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

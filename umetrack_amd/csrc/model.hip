@@ -326,11 +326,16 @@ static int run_blocks(umt_model* m, size_t b0, size_t b1, int n, float*& x, floa
   for (size_t i = b0; i < b1; ++i) {
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
-    UMT_TRY(launch_conv(B.conv1, x, n, hw, hw, nullptr, t, s));
     const float* res = x;
-    if (B.has_down) {
-      UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, d, s));
+    if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
+      UMT_TRY(launch_conv_s2_fused(B.conv1, &B.down, x, n, hw, hw, t, d, s));     // conv1 and the down-sample branch
       res = d;
+    } else {
+      UMT_TRY(launch_conv(B.conv1, x, n, hw, hw, nullptr, t, s));
+      if (B.has_down) {
+        UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, d, s));
+        res = d;
+      }
     }
     const int hw2 = hw / B.conv1.stride;
     UMT_TRY(launch_conv(B.conv2, t, n, hw2, hw2, res, y, s));
@@ -381,11 +386,16 @@ static int run_blocks_bf16(umt_model* m, size_t b0, size_t b1, int n, uint16_t*&
   for (size_t i = b0; i < b1; ++i) {
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
-    UMT_TRY(launch_conv_bf16(B.conv1, x, n, hw, hw, nullptr, t, 0, s));
     const uint16_t* res = x;
-    if (B.has_down) {
-      UMT_TRY(launch_conv_bf16(B.down, x, n, hw, hw, nullptr, d, 0, s));
+    if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
+      UMT_TRY(launch_conv_s2_fused_bf16(B.conv1, &B.down, x, n, hw, hw, t, d, s));
       res = d;
+    } else {
+      UMT_TRY(launch_conv_bf16(B.conv1, x, n, hw, hw, nullptr, t, 0, s));
+      if (B.has_down) {
+        UMT_TRY(launch_conv_bf16(B.down, x, n, hw, hw, nullptr, d, 0, s));
+        res = d;
+      }
     }
     const int hw2 = hw / B.conv1.stride;
     UMT_TRY(launch_conv_bf16(B.conv2, t, n, hw2, hw2, res, y, 0, s));

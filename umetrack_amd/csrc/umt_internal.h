@@ -82,9 +82,17 @@ struct ConvLayer {
 int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
                 float* out, hipStream_t stream);
 
+// conv1 (3x3 stride 2) of a stage's first block fused with its 1x1 stride-2 down-sample branch (ds may be null)
+bool conv_s2_fused_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w);
+int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* in, int n, int h, int w, float* out,
+                         float* ds_out, hipStream_t stream);
+
 // conv_bf16.hip: bf16 rows in, bf16 (or fp32 when out_f32) rows out, fp32 accumulation and epilogue
 int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual,
                      void* out, int out_f32, hipStream_t stream);
+
+int launch_conv_s2_fused_bf16(const ConvLayer& c1, const ConvLayer* ds, const uint16_t* in, int n, int h, int w,
+                              uint16_t* out, uint16_t* ds_out, hipStream_t stream);
 
 // conv_thin.hip: persistent bf16 kernel for the 32->32 stride-1 3x3 layers (weights in registers)
 extern int g_conv_thin;
