@@ -11,6 +11,9 @@
 // reported separately from the fp32 parity mode (tests/test_gpu_bf16.py states the tolerance).
 #include "umt_internal.h"
 
+#ifndef UMT_CFG128H
+#define UMT_CFG128H 2, 2, 2, 2
+#endif
 #ifndef UMT_CFG64H
 #define UMT_CFG64H 2, 2, 2, 1
 #endif
@@ -519,7 +522,7 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
   UMT_REQUIRE(M < (int64_t)1 << 31 && (int64_t)n * h * w < (int64_t)1 << 31, UMT_ERR_INVALID, "conv_bf16: too many pixels");
   a.M = (int)M;
   const bool halo = L.taps == 9 && L.stride == 1 && w <= 48;
-  if (L.cout_w % 128 == 0) halo ? launch_halo_h<2, 2, 2, 2>(a, stream) : launch_gather_h<2, 2, 2, 2>(a, stream);
+  if (L.cout_w % 128 == 0) halo ? launch_halo_h<UMT_CFG128H>(a, stream) : launch_gather_h<2, 2, 2, 2>(a, stream);
   else if (L.cout_w == 96) halo ? launch_halo_h<4, 1, 1, 3>(a, stream) : launch_gather_h<4, 1, 1, 3>(a, stream);
   else if (L.cout_w == 64) halo ? launch_halo_h<UMT_CFG64H>(a, stream) : launch_gather_h<2, 2, 2, 1>(a, stream);
   else if (L.cout_w == 32) halo ? launch_halo_h<4, 1, 1, 1>(a, stream) : launch_gather_h<4, 1, 1, 1>(a, stream);
