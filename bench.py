@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU (weak scaling)")
     ap.add_argument("--frames-per-recording", type=int, default=64)
-    ap.add_argument("--chunk-frames", type=int, default=2048)
+    ap.add_argument("--chunk-frames", type=int, default=4096)
     ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
                     help="backbone arithmetic; fp32 is the reference's and the headline line, bf16 is a separate mode")
