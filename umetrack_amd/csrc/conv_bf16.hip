@@ -51,63 +51,74 @@ __device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast
 
 // Epilogue.  The residual rows of ALL the wave's tiles are requested first (one exposed memory latency per
 // workgroup instead of one per tile: the residual is the block input, long evicted from L2 when conv2
-// ends), then each accumulator tile goes through the wave's LDS patch (transpose) so that a lane owns 4
-// consecutive channels of a pixel row: conv bias -> BN scale/shift -> residual -> ReLU -> one rounding.
+// ends), then each accumulator tile goes through the wave's LDS patch (transpose) so that a lane owns 8
+// consecutive channels of a pixel row - 16 bytes of bf16, the widest store: conv bias -> BN scale/shift ->
+// residual -> ReLU -> one rounding.  Four lanes complete a 64-byte row, 16 rows per pass, two passes per tile.
 template <int TM, int TN>
-__device__ __forceinline__ void load_residual_h(uint2 (&res)[TN][TM][4], int lane, int mwave, int cowave,
+__device__ __forceinline__ void load_residual_h(uint4 (&res)[TN][TM][2], int lane, int mwave, int cowave,
                                                 const ConvArgsH& a) {
-  const int q = lane & 7, rsub = lane >> 3;
+  const int q = lane & 3, rsub = lane >> 2;
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int m = mwave + i * 32 + 8 * k + rsub;
-        const int co = cowave + j * 32 + 4 * q;
+      for (int k = 0; k < 2; ++k) {
+        const int m = mwave + i * 32 + 16 * k + rsub;
+        const int co = cowave + j * 32 + 8 * q;
         const bool ok = a.residual && m < a.M && co < a.cout_s;
         const size_t o = ok ? (size_t)m * a.cout_s + co : 0;
-        res[j][i][k] = make_uint2(0u, 0u);
-        if (ok) res[j][i][k] = *reinterpret_cast<const uint2*>(a.residual + o);
+        res[j][i][k] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok) res[j][i][k] = *reinterpret_cast<const uint4*>(a.residual + o);
       }
 }
 
+__device__ __forceinline__ void affine4(float4& v, const float4& cb, const float4& cs, const float4& ch) {
+  v.x = (v.x + cb.x) * cs.x + ch.x;
+  v.y = (v.y + cb.y) * cs.y + ch.y;
+  v.z = (v.z + cb.z) * cs.z + ch.z;
+  v.w = (v.w + cb.w) * cs.w + ch.w;
+}
+
 template <bool PRE>
-__device__ __forceinline__ void store_tile_h(const f32x16& acc, const uint2 (&res)[4], float* patch, int lane, int mbase,
+__device__ __forceinline__ void store_tile_h(const f32x16& acc, const uint4 (&res)[2], float* patch, int lane, int mbase,
                                              int cobase, const ConvArgsH& a) {
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + li] = acc[r];
   __builtin_amdgcn_wave_barrier();
-  const int q = lane & 7, rsub = lane >> 3;
-  const int co = cobase + 4 * q;
+  const int q = lane & 3, rsub = lane >> 2;
+  const int co = cobase + 8 * q;
   if (co < a.cout_s) {
-    const float4 cb = *reinterpret_cast<const float4*>(a.bias + co);
-    const float4 cs = *reinterpret_cast<const float4*>(a.scale + co);
-    const float4 ch = *reinterpret_cast<const float4*>(a.shift + co);
+    const float4 cb0 = *reinterpret_cast<const float4*>(a.bias + co), cb1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+    const float4 cs0 = *reinterpret_cast<const float4*>(a.scale + co), cs1 = *reinterpret_cast<const float4*>(a.scale + co + 4);
+    const float4 ch0 = *reinterpret_cast<const float4*>(a.shift + co), ch1 = *reinterpret_cast<const float4*>(a.shift + co + 4);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = 8 * k + rsub;
+    for (int k = 0; k < 2; ++k) {
+      const int row = 16 * k + rsub;
       const int m = mbase + row;
       if (m < a.M) {
-        float4 v = *reinterpret_cast<const float4*>(patch + row * LDP + 4 * q);
+        float4 v = *reinterpret_cast<const float4*>(patch + row * LDP + 8 * q);
+        float4 u = *reinterpret_cast<const float4*>(patch + row * LDP + 8 * q + 4);
         const size_t o = (size_t)m * a.cout_s + co;
-        v.x = (v.x + cb.x) * cs.x + ch.x;
-        v.y = (v.y + cb.y) * cs.y + ch.y;
-        v.z = (v.z + cb.z) * cs.z + ch.z;
-        v.w = (v.w + cb.w) * cs.w + ch.w;
+        affine4(v, cb0, cs0, ch0);
+        affine4(u, cb1, cs1, ch1);
         if (PRE || a.residual) {
-          const uint2 rr = PRE ? res[k] : *reinterpret_cast<const uint2*>(a.residual + o);
+          const uint4 rr = PRE ? res[k] : *reinterpret_cast<const uint4*>(a.residual + o);
           v.x += bf16_lo(rr.x); v.y += bf16_hi(rr.x); v.z += bf16_lo(rr.y); v.w += bf16_hi(rr.y);
+          u.x += bf16_lo(rr.z); u.y += bf16_hi(rr.z); u.z += bf16_lo(rr.w); u.w += bf16_hi(rr.w);
         }
         if (a.relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
         }
-        if (a.out_f32)
+        if (a.out_f32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = v;
-        else
-          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(a.out) + o) =
-              make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o + 4) = u;
+        } else {
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(a.out) + o) =
+              make_uint4(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w), pack_bf16x2(u.x, u.y), pack_bf16x2(u.z, u.w));
+        }
       }
     }
   }
@@ -119,7 +130,7 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const uint2 (&re
 template <int TM, int TN, bool PRE>
 __device__ __forceinline__ void epilogue_h(const f32x16 (&acc)[TM][TN], float* patch, int lane, int mwave, int cowave,
                                            const ConvArgsH& a) {
-  uint2 res[TN][TM][4];
+  uint4 res[TN][TM][2];
   if (PRE) load_residual_h<TM, TN>(res, lane, mwave, cowave, a);
 #pragma unroll
   for (int j = 0; j < TN; ++j)

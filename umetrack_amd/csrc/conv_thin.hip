@@ -114,10 +114,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
       for (int c = 0; c < 2; ++c)
         breg[tap][c] = *reinterpret_cast<const uint4*>(wp + ((size_t)((tap * 2 + c) * 2 + lh) * 32 + li) * 8);
   }
-  const int q = lane & 7, rsub = lane >> 3;
-  const float4 cb = *reinterpret_cast<const float4*>(a.bias + 4 * q);
-  const float4 cs = *reinterpret_cast<const float4*>(a.scale + 4 * q);
-  const float4 ch = *reinterpret_cast<const float4*>(a.shift + 4 * q);
+  // epilogue: a lane owns 8 consecutive channels (16 bytes of bf16) of a pixel row, 16 rows per pass
+  const int q = lane & 3, rsub = lane >> 2;
+  const float4 cb0 = *reinterpret_cast<const float4*>(a.bias + 8 * q), cb1 = *reinterpret_cast<const float4*>(a.bias + 8 * q + 4);
+  const float4 cs0 = *reinterpret_cast<const float4*>(a.scale + 8 * q), cs1 = *reinterpret_cast<const float4*>(a.scale + 8 * q + 4);
+  const float4 ch0 = *reinterpret_cast<const float4*>(a.shift + 8 * q), ch1 = *reinterpret_cast<const float4*>(a.shift + 8 * q + 4);
 
   const GroupWalk gw = group_walk(a.ntiles, group);
   const GroupWalk g0 = group_walk(a.ntiles, 0);
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
   __syncthreads();
 
   f32x16 acc[TM];
-  uint2 res[TM][4];
+  uint4 res[TM][2];
   for (int ph = 0; ph < nphase; ++ph) {
     const int j = (ph - group) >> 1;
     const bool mfma_phase = ((ph - group) & 1) == 0;
@@ -170,10 +171,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int m = mw + i * 32 + 8 * k + rsub;
-              const size_t off = m < a.M ? (size_t)m * 32 + 4 * q : 0;
-              res[i][k] = *reinterpret_cast<const uint2*>(resid + off);
+            for (int k = 0; k < 2; ++k) {
+              const int m = mw + i * 32 + 16 * k + rsub;
+              const size_t off = m < a.M ? (size_t)m * 32 + 8 * q : 0;
+              res[i][k] = *reinterpret_cast<const uint4*>(resid + off);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -207,25 +208,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
           for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][r];
           __builtin_amdgcn_wave_barrier();
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int row = 8 * k + rsub;
+          for (int k = 0; k < 2; ++k) {
+            const int row = 16 * k + rsub;
             const int m = mw + i * 32 + row;
-            float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 4 * q);
-            v.x = (v.x + cb.x) * cs.x + ch.x;
-            v.y = (v.y + cb.y) * cs.y + ch.y;
-            v.z = (v.z + cb.z) * cs.z + ch.z;
-            v.w = (v.w + cb.w) * cs.w + ch.w;
+            float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+            float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+            v.x = (v.x + cb0.x) * cs0.x + ch0.x; v.y = (v.y + cb0.y) * cs0.y + ch0.y;
+            v.z = (v.z + cb0.z) * cs0.z + ch0.z; v.w = (v.w + cb0.w) * cs0.w + ch0.w;
+            u.x = (u.x + cb1.x) * cs1.x + ch1.x; u.y = (u.y + cb1.y) * cs1.y + ch1.y;
+            u.z = (u.z + cb1.z) * cs1.z + ch1.z; u.w = (u.w + cb1.w) * cs1.w + ch1.w;
             if (RES) {
-              const uint2 rr = res[i][k];
+              const uint4 rr = res[i][k];
               v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
               v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+              u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
+              u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
             }
             if (a.relu) {
               v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
             }
             if (m < a.M)
-              *reinterpret_cast<uint2*>(out + (size_t)m * 32 + 4 * q) =
-                  make_uint2(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w));
+              *reinterpret_cast<uint4*>(out + (size_t)m * 32 + 8 * q) =
+                  make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y),
+                             thin_pack_bf16x2(u.z, u.w));
           }
           __builtin_amdgcn_wave_barrier();
         }
