@@ -22,9 +22,10 @@ hw = 48
 for cin, cout, st, nb in [(32, 32, 1, 2), (32, 64, 2, 3), (64, 128, 2, 5), (128, 256, 2, 2)]:
     for b in range(nb):
         ci, s = (cin, st) if b == 0 else (cout, 1)
-        L.append((f"c1 {ci}->{cout} hw{hw} s{s}", conv(ci, cout, hw, 3, s)))
-        if b == 0 and st != 1:
-            L.append((f"ds {ci}->{cout}", conv(ci, cout, hw, 1, s)))
+        if b == 0 and st != 1:      # conv1 and the 1x1 down-sample branch are one launch (conv3x3s2_ds_*)
+            L.append((f"c1+ds {ci}->{cout} hw{hw} s{s}", conv(ci, cout, hw, 3, s) + conv(ci, cout, hw, 1, s)))
+        else:
+            L.append((f"c1 {ci}->{cout} hw{hw} s{s}", conv(ci, cout, hw, 3, s)))
         hw //= s
         L.append((f"c2 {cout}->{cout} hw{hw}", conv(cout, cout, hw, 3)))
 L.append(("proj", conv(256, 72, 6, 1)))
