@@ -36,7 +36,15 @@ struct ConvArgsH {
   int cin_s, cout_s, cout_w;
   int stride, taps, relu;
   int M;
+  unsigned mg_hw, mg_w;   // floor(2^32 / (H*W)) + 1 and floor(2^32 / W) + 1: division by multiplication in the kernels
 };
+
+// floor(m / d) for 0 <= m < 2^31 and 1 <= d <= 65536 with mg = floor(2^32 / d) + 1: the estimate is exact or one too high
+__device__ __forceinline__ int div_magic(int m, int d, unsigned mg) {
+  int q = (int)__umulhi((unsigned)m, mg);
+  if (q * d > m) --q;
+  return q;
+}
 
 constexpr int KCH = 32;          // channels per staged chunk
 constexpr int LDH = 40;          // bf16 per LDS row (80 B): 16 consecutive rows hit 16 distinct 16-B slots
@@ -72,6 +80,9 @@ __device__ __forceinline__ void load_residual_h(uint4 (&res)[TN][TM][2], int lan
         if (ok) res[j][i][k] = *reinterpret_cast<const uint4*>(a.residual + o);
       }
 }
+
+// max(v, 0) as one integer max on the bits (negative floats are negative integers; -0 -> +0)
+__device__ __forceinline__ float relu1(float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0)); }
 
 __device__ __forceinline__ void affine4(float4& v, const float4& cb, const float4& cs, const float4& ch) {
   v.x = (v.x + cb.x) * cs.x + ch.x;
@@ -109,8 +120,8 @@ __device__ __forceinline__ void store_tile_h(const f32x16& acc, const uint4 (&re
           u.x += bf16_lo(rr.z); u.y += bf16_hi(rr.z); u.z += bf16_lo(rr.w); u.w += bf16_hi(rr.w);
         }
         if (a.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+          v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
+          u.x = relu1(u.x); u.y = relu1(u.y); u.z = relu1(u.z); u.w = relu1(u.w);
         }
         if (a.out_f32) {
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + o) = v;
@@ -258,8 +269,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wm * TM + i) * 32 + li;
     const bool live = m < a.M;
-    const int rem = (live ? m : 0) % (H * W);
-    const int y = rem / W, x = rem - y * W;
+    const int mm = live ? m : 0;
+    const int rem = mm - div_magic(mm, H * W, a.mg_hw) * (H * W);
+    const int y = div_magic(rem, W, a.mg_w), x = rem - y * W;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -286,13 +298,21 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
   // ring of three tap slots (9 taps per chunk, so the slot of a tap is static): the fragments of tap t+2
   // are requested while tap t runs - two taps are only 8-16 MFMAs, about one L2 round trip
   uint4 bring[3][2][TN];
+  // buffer loads: resource (base of the packed weights) and the (tap, channel group) offset are scalar, the
+  // lane offset is one 32-bit VGPR computed once - no per-load 64-bit VALU address arithmetic
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (int)(n0 * 16 + wlane_off);
   auto load_b = [&](uint4 (&dst)[2][TN], int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int c16 = min(chunk * 2 + c, c16_total - 1);
-      const char* wu = wblock + tap * w_tap + c16 * w_c16;
+      const int soff = (int)(tap * w_tap + c16 * w_c16);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const uint4*>(wu + j * 512 + wlane_off);
+      for (int j = 0; j < TN; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + j * 512, soff, 0);
+        dst[c][j] = make_uint4(v.x, v.y, v.z, v.w);
+      }
     }
   };
   load_b(bring[0], 0, 0);
@@ -532,6 +552,8 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
   const int64_t M = (int64_t)n * a.Ho * a.Wo;
   UMT_REQUIRE(M < (int64_t)1 << 31 && (int64_t)n * h * w < (int64_t)1 << 31, UMT_ERR_INVALID, "conv_bf16: too many pixels");
   a.M = (int)M;
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
   const bool halo = L.taps == 9 && L.stride == 1 && w <= 48;
   if (L.cout_w % 128 == 0) halo ? launch_halo_h<UMT_CFG128H>(a, stream) : launch_gather_h<2, 2, 2, 2>(a, stream);
   else if (L.cout_w == 96) halo ? launch_halo_h<4, 1, 1, 3>(a, stream) : launch_gather_h<4, 1, 1, 3>(a, stream);
