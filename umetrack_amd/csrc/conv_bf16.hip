@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_bf16(ConvS2ArgsH g) {
   const int nchunks = (a.cin_s + KCH - 1) / KCH;
 
   auto centre = [&](int m) {
-    const int R = m / Wo, xo = m - R * Wo;
+    const int R = div_magic(m, Wo, a.mg_w), xo = m - R * Wo;        // for this kernel mg_w / mg_hw divide by Wo / Ho
     return 2 * W * R + 2 * xo;
   };
   const int m_last = min(m0 + BM, a.M) - 1;
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_bf16(ConvS2ArgsH g) {
     const int m = m0 + wm * 32 + li;
     const bool live = m < a.M;
     const int mm = live ? m : m0;
-    const int R = mm / Wo, xo = mm - R * Wo, yo = R % Ho;
+    const int R = div_magic(mm, Wo, a.mg_w), xo = mm - R * Wo, yo = R - div_magic(R, Ho, a.mg_hw) * Ho;
     const int base = 2 * W * R + 2 * xo - g0;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -436,18 +436,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_bf16(ConvS2ArgsH g) {
     for (int r = 0; r < 16; ++r) { acc[0][j][r] = 0.f; accd[0][j][r] = 0.f; }
 
   const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 16);
-  const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 8);
-  const char* dblock = reinterpret_cast<const char*>(g.ds_w + (size_t)n0 * 8);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(DS ? g.ds_w : a.w), 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (int)(n0 * 16 + wlane_off);
   const size_t w_c16 = (size_t)2 * a.cout_w * 16;
   const size_t w_tap = (size_t)c16_total * w_c16;
   uint4 bring[3][2][TN], bds[2][TN];
-  auto load_b = [&](uint4 (&dst)[2][TN], const char* blk, int tap, int chunk) {
+  auto load_b = [&](uint4 (&dst)[2][TN], __amdgpu_buffer_rsrc_t blk, int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int c16 = min(chunk * 2 + c, c16_total - 1);
-      const char* wu = blk + tap * w_tap + c16 * w_c16;
+      const int soff = (int)(tap * w_tap + c16 * w_c16);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const uint4*>(wu + j * 512 + wlane_off);
+      for (int j = 0; j < TN; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(blk, wvoff + j * 512, soff, 0);
+        dst[c][j] = make_uint4(v.x, v.y, v.z, v.w);
+      }
     }
   };
   load_b(bring[0], wblock, 0, 0);
@@ -576,6 +581,8 @@ int launch_conv_s2_fused_bf16(const ConvLayer& c1, const ConvLayer* ds, const ui
   a.cin_s = c1.cin_s; a.cout_s = c1.cout_s; a.cout_w = c1.cout_w; a.stride = 2; a.taps = 9; a.relu = c1.relu;
   UMT_REQUIRE((int64_t)n * h * w < ((int64_t)1 << 31) - 65536, UMT_ERR_INVALID, "conv_s2_bf16: too many pixels");
   a.M = n * a.Ho * a.Wo;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.Wo) + 1u;      // this kernel divides by Wo and Ho
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.Ho) + 1u;
   g.ds_w = ds ? ds->wh : nullptr; g.ds_bias = ds ? ds->bias : nullptr; g.ds_scale = ds ? ds->scale : nullptr;
   g.ds_shift = ds ? ds->shift : nullptr; g.ds_out = ds_out;
   size_t lds = (size_t)(S2H_ROWS_MAX + 1) * LDH * 2;

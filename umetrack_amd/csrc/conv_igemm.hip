@@ -57,7 +57,15 @@ struct ConvArgs {
   int cin_s, cout_s, cout_w;
   int stride, taps, relu;
   int M;  // n * Ho * Wo output pixels
+  unsigned mg_hw, mg_w;   // floor(2^32 / (H*W)) + 1 and floor(2^32 / W) + 1 (division by multiplication)
 };
+
+// floor(m / d) for 0 <= m < 2^31 and 1 <= d <= 65536 with mg = floor(2^32 / d) + 1: the estimate is exact or one too high
+__device__ __forceinline__ int div_magic32(int m, int d, unsigned mg) {
+  int q = (int)__umulhi((unsigned)m, mg);
+  if (q * d > m) --q;
+  return q;
+}
 
 constexpr int KC = 32;        // input channels staged per step
 constexpr int LDA = KC + 4;   // padded A row (floats): 16 consecutive pixels hit 16 distinct 16-B slots
@@ -280,8 +288,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_halo_f32(ConvArgs a) {
   for (int i = 0; i < TM; ++i) {
     const int m = m0 + (wm * TM + i) * 32 + li;
     const bool live = m < a.M;
-    const int rem = (live ? m : 0) % (H * W);
-    const int y = rem / W, x = rem - y * W;
+    const int mm = live ? m : 0;
+    const int rem = mm - div_magic32(mm, H * W, a.mg_hw) * (H * W);
+    const int y = div_magic32(rem, W, a.mg_w), x = rem - y * W;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -309,15 +318,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_halo_f32(ConvArgs a) {
   const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 4);
   const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float);   // bytes per c8 group
   const size_t w_tap = (size_t)c8_total * w_c8;                   // bytes per tap
+  // buffer loads: resource (base of the packed weights) and the (tap, channel group) offset are scalar, the
+  // lane offset is one 32-bit VGPR computed once - no per-load 64-bit VALU address arithmetic
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (int)(n0 * 16 + wlane_off);
+  (void)wblock;
   float4 bcur[4][TN], bnext[4][TN];
   auto load_b = [&](float4 (&dst)[4][TN], int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int c8 = min(chunk * 4 + c, c8_total - 1);
-      const char* wu = wblock + tap * w_tap + c8 * w_c8;          // wave-uniform
+      const int soff = (int)(tap * w_tap + c8 * w_c8);            // wave-uniform
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        dst[c][j] = *reinterpret_cast<const float4*>(wu + j * 512 + wlane_off);
+      for (int j = 0; j < TN; ++j) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + j * 512, soff, 0));
+        dst[c][j] = make_float4(v.x, v.y, v.z, v.w);
+      }
     }
   };
   load_b(bcur, 0, 0);
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
 
   // centre-tap input pixel of output pixel m: 2W * (global output row) + 2 * xo
   auto centre = [&](int m) {
-    const int R = m / Wo, xo = m - R * Wo;
+    const int R = div_magic32(m, Wo, a.mg_w), xo = m - R * Wo;      // for this kernel mg_w / mg_hw divide by Wo / Ho
     return 2 * W * R + 2 * xo;
   };
   const int m_last = min(m0 + BM, a.M) - 1;
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
     const int m = m0 + wm * 32 + li;
     const bool live = m < a.M;
     const int mm = live ? m : m0;
-    const int R = mm / Wo, xo = mm - R * Wo, yo = R % Ho;
+    const int R = div_magic32(mm, Wo, a.mg_w), xo = mm - R * Wo, yo = R - div_magic32(R, Ho, a.mg_hw) * Ho;
     const int base = 2 * W * R + 2 * xo - g0;            // LDS row of the centre tap
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
@@ -464,18 +482,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
     for (int r = 0; r < 16; ++r) { acc[0][j][r] = 0.f; accd[0][j][r] = 0.f; }
 
   const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 4 * sizeof(float));
-  const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 4);
-  const char* dblock = reinterpret_cast<const char*>(g.ds_w + (size_t)n0 * 4);
   const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float);
   const size_t w_tap = (size_t)c8_total * w_c8;
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DS ? g.ds_w : a.w), 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (int)(n0 * 16 + wlane_off);
   float4 bcur[4][TN], bnext[4][TN], bds[4][TN];
-  auto load_b = [&](float4 (&dst)[4][TN], const char* blk, int tap, int chunk) {
+  auto load_b = [&](float4 (&dst)[4][TN], __amdgpu_buffer_rsrc_t blk, int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int c8 = min(chunk * 4 + c, c8_total - 1);
-      const char* wu = blk + tap * w_tap + c8 * w_c8;
+      const int soff = (int)(tap * w_tap + c8 * w_c8);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) dst[c][j] = *reinterpret_cast<const float4*>(wu + j * 512 + wlane_off);
+      for (int j = 0; j < TN; ++j) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(blk, wvoff + j * 512, soff, 0));
+        dst[c][j] = make_float4(v.x, v.y, v.z, v.w);
+      }
     }
   };
   load_b(bcur, wblock, 0, 0);
@@ -590,6 +614,8 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   UMT_REQUIRE(M < (int64_t)1 << 31 && (int64_t)n * h * w < (int64_t)1 << 31, UMT_ERR_INVALID,
               "conv: %lld output pixels exceed the 32-bit pixel index", (long long)M);
   a.M = (int)M;
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
   static const bool force_gather = getenv("UMT_CONV_GATHER") != nullptr;   // A/B switch for profiling
   if (L.taps == 9 && L.stride == 1 && w <= 48 && !force_gather) {
     if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
@@ -632,6 +658,8 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
   const int64_t M = (int64_t)n * a.Ho * a.Wo;
   UMT_REQUIRE((int64_t)n * h * w < ((int64_t)1 << 31) - 65536, UMT_ERR_INVALID, "conv_s2: too many pixels");
   a.M = (int)M;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.Wo) + 1u;      // this kernel divides by Wo and Ho
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)a.Ho) + 1u;
   g.ds_w = ds ? ds->w : nullptr; g.ds_bias = ds ? ds->bias : nullptr; g.ds_scale = ds ? ds->scale : nullptr;
   g.ds_shift = ds ? ds->shift : nullptr; g.ds_out = ds_out;
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);

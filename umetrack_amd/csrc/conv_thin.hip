@@ -37,7 +37,14 @@ struct ThinArgs {
   void* out;             // rows [M][32]
   int H, W, M, relu;
   int ntiles;
+  unsigned mg_hw, mg_w;  // floor(2^32 / (H*W)) + 1 and floor(2^32 / W) + 1
 };
+
+__device__ __forceinline__ int thin_div(int m, int d, unsigned mg) {      // floor(m / d), 0 <= m < 2^31
+  int q = (int)__umulhi((unsigned)m, mg);
+  if (q * d > m) --q;
+  return q;
+}
 
 constexpr int T_LDH = 40;   // bf16 per bf16 LDS row (80 B)
 constexpr int T_LDP = 36;   // floats per row of the epilogue patch
@@ -52,11 +59,11 @@ __device__ __forceinline__ void tile_walk(int ntiles, int& first, int& step, int
   end = min((xcd + 1) * tpx, ntiles);
 }
 
-__device__ __forceinline__ unsigned border_mask(int m, int M, int H, int W) {
+__device__ __forceinline__ unsigned border_mask(int m, int M, int H, int W, unsigned mg_hw, unsigned mg_w) {
   unsigned mk = 0;
   if (m < M) {
-    const int rem = m % (H * W);
-    const int y = rem / W, x = rem - y * W;
+    const int rem = m - thin_div(m, H * W, mg_hw) * (H * W);
+    const int y = thin_div(rem, W, mg_w), x = rem - y * W;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
         int arow[TM][9];      // byte offset of the lane's operand row per tap; the zero row where padded
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const unsigned mk = border_mask(mw + i * 32 + li, a.M, H, W);
+          const unsigned mk = border_mask(mw + i * 32 + li, a.M, H, W, a.mg_hw, a.mg_w);
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap)
             arow[i][tap] = ((((mk >> tap) & 1u) ? (wave * TM + i) * 32 + li + (tap / 3) * W + (tap % 3) : rows) * T_LDH + 8 * lh) * 2;
@@ -283,6 +290,8 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
   a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift; a.residual = residual; a.out = out;
   a.H = h; a.W = w; a.M = (int)M; a.relu = L.relu;
   a.ntiles = (int)((M + 128 * TM - 1) / (128 * TM));
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
   const size_t lds = 2 * ((((size_t)(128 * TM + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
   const dim3 grid(grid_for(a.ntiles, 1));
   auto kern = residual ? conv3x3_thin32_bf16<TM, true> : conv3x3_thin32_bf16<TM, false>;
