@@ -107,8 +107,11 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float4 (&res
           const float4 rr = PRE ? res[k] : *reinterpret_cast<const float4*>(a.residual + o);
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
-        if (a.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        if (a.relu) {      // max(v, 0) as one integer max on the bits (negative floats are negative integers; -0 -> +0)
+          v.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.x), 0));
+          v.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.y), 0));
+          v.z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.z), 0));
+          v.w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.w), 0));
         }
         if (!UMT_X_NOSTORE || v.x == 123.456f) *reinterpret_cast<float4*>(a.out + o) = v;
       }
