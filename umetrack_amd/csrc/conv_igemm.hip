@@ -638,6 +638,16 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   return 0;
 }
 
+static unsigned char g_s2_lds_done[2][64];
+int conv_thin_prepare_device();
+
+int conv_prepare_device() {
+  const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, false>), lds, g_s2_lds_done[0]));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, true>), lds, g_s2_lds_done[1]));
+  return conv_thin_prepare_device();
+}
+
 // conv1 (3x3, stride 2) of a stage's first block, fused with its down-sample 1x1 (ds may be null).
 bool conv_s2_fused_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w) {
   static const bool off = getenv("UMT_CONV_NOS2") != nullptr;     // A/B switch for profiling
@@ -670,7 +680,7 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
   // weight double buffers of both convolutions for two tiles and spill
   dim3 grid((a.M + S2_BM - 1) / S2_BM, c1.cout_w / 64);
   void (*kern)(ConvS2Args) = ds ? conv3x3s2_ds_f32<1, true> : conv3x3s2_ds_f32<1, false>;
-  UMT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, ds ? g_s2_lds_done[1] : g_s2_lds_done[0]));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -280,6 +280,16 @@ static int grid_for(int ntiles, int per_cu) {
 #define UMT_THIN_TM 2
 #endif
 
+static unsigned char g_thin_lds_done[2][64];
+static size_t thin_lds_bytes(int tm, int w) {
+  return 2 * ((((size_t)(128 * tm + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
+}
+int conv_thin_prepare_device() {      // largest request: W = 48
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, false>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[0]));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, true>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[1]));
+  return 0;
+}
+
 int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual,
                           uint16_t* out, hipStream_t stream) {
   constexpr int TM = UMT_THIN_TM;
@@ -292,10 +302,10 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
   a.ntiles = (int)((M + 128 * TM - 1) / (128 * TM));
   a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
-  const size_t lds = 2 * ((((size_t)(128 * TM + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
+  const size_t lds = thin_lds_bytes(TM, w);
   const dim3 grid(grid_for(a.ntiles, 1));
   auto kern = residual ? conv3x3_thin32_bf16<TM, true> : conv3x3_thin32_bf16<TM, false>;
-  UMT_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), thin_lds_bytes(TM, 48), residual ? g_thin_lds_done[1] : g_thin_lds_done[0]));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;

@@ -567,6 +567,7 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
   UMT_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, UMT_ERR_UNSUPPORTED,
               "libumetrack_hip is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
   UMT_CHECK_HIP(hipSetDevice(device));
+  UMT_TRY(conv_prepare_device());      // raise the dynamic-LDS limit of the kernels that need > 64 KB, once per device
 
   std::vector<float> host;
   std::vector<Packed> packed;

@@ -37,6 +37,20 @@ int set_error(int code, const char* fmt, ...);
   } while (0)
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
+// device.  `done` is the caller's per-kernel table (one flag per device); conv_prepare_device() raises the
+// attribute of every such kernel at umt_model_finalize, so the launch path normally only reads the flag.
+static inline int ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned char (&done)[64]) {
+  int dev = 0;
+  UMT_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64 || !done[dev]) {
+    UMT_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    if (dev >= 0 && dev < 64) done[dev] = 1;
+  }
+  return 0;
+}
+int conv_prepare_device();      // conv_igemm.hip + conv_thin.hip: raise the attribute for the current device
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 #ifdef __HIPCC__
