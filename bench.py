@@ -210,6 +210,33 @@ def cpu_baseline(pipe, n_hands, budget_s=12.0):
                       f"oracle warp(cv2 fixed-point)+network fp32+FK, {dt:.2f} s/pass"}, pred, mpjpe
 
 
+def stream_main(args, rank, world, dev):
+    """configs[4]: one pass over the stream = the timed region; --steps / --warmup count whole passes."""
+    from umetrack_amd.stream import StreamRunner
+    runner = StreamRunner(dev, precision=args.precision, chunk_frames=args.frames, frames_per_recording=args.frames_per_recording)
+    runner.run(min(args.stream_frames, args.frames * world), rank, world)          # warm-up: one chunk per rank
+    for _ in range(max(args.warmup - 1, 0)):
+        runner.run(args.stream_frames, rank, world)
+    elapsed, res = 0.0, None
+    for _ in range(args.steps):
+        res = runner.run(args.stream_frames, rank, world)
+        elapsed += udist.max_over_ranks(res.seconds, dev if world > 1 else None)
+    fin = mu.finalize_partials(res.partials)
+    if rank != 0:
+        return
+    print(json.dumps({
+        "metric": "hand-frames/sec (4-view)", "value": 2 * args.stream_frames * args.steps / elapsed, "unit": "hand-frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[4]: synthetic stream of {args.stream_frames} frames x 2 hands x 2 views, produced "
+                               f"on the device in chunks of {args.frames} frames, sharded by contiguous chunk over {world} GPU(s), "
+                               "one all-reduce of the 108 float64 metric partials; the time includes generating the stream",
+                   "stream_frames": args.stream_frames, "chunk_frames": args.frames,
+                   "chunks_rank0": list(res.chunks_local), "weights": "seeded random (pretrained_weights.torch not distributed)"},
+        "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa, "n_valid": fin.n_valid, "n_total": fin.n_total}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +250,9 @@ def main():
                     help="backbone arithmetic; fp32 is the reference's and the headline line, bf16 is a separate mode")
     ap.add_argument("--host-crop-cameras", action="store_true",
                     help="use crop cameras precomputed on the host instead of generating them on the GPU each step")
+    ap.add_argument("--stream-frames", type=int, default=0,
+                    help="run BASELINE.json configs[4] instead: a synthetic stream of this many frames, produced on the "
+                         "device in chunks of --frames, sharded over the ranks by contiguous chunk (STRONG scaling)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host->device copy-rate measurement")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
@@ -238,6 +268,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    if args.stream_frames > 0:
+        return stream_main(args, rank, world, dev)
 
     pipe = Pipeline(args.frames, args.frames_per_recording, args.chunk_frames, seed=rank, device=dev,
                     precision=args.precision, host_crop_cameras=args.host_crop_cameras)

@@ -171,3 +171,37 @@ def test_metric_reduction_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "OK 2" in out.stdout
+
+
+_STREAM_WORKER = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from umetrack_amd import dist as udist
+from umetrack_amd.stream import chunk_plan, run_sharded
+rank, world, _ = udist.init_from_env("gloo")
+n_chunks, last = chunk_plan(1_000_000, 4096, 64)
+assert (n_chunks, last) == (245, 576)
+seen = []
+def run_chunk(c):                                   # stands in for StreamRunner.run_chunk on CPU ranks
+    seen.append(c)
+    n = last if c == n_chunks - 1 else 4096
+    return torch.tensor([float(c), 2.0 * n], dtype=torch.float64)
+acc, (c0, c1) = run_sharded(n_chunks, rank, world, run_chunk, torch.zeros(2, dtype=torch.float64))
+assert seen == list(range(c0, c1)) and 0 <= c1 - c0 - n_chunks // world <= 1
+assert acc.tolist() == [n_chunks * (n_chunks - 1) / 2, 2.0 * 1_000_000], acc
+print("STREAM OK", world)
+udist.barrier()
+'''
+
+
+def test_stream_sharding_world_size_2_gloo(tmp_path):
+    """configs[4]: contiguous chunk ranges per rank, one all-reduce; the chunk step is stubbed (no GPU here)."""
+    script = tmp_path / "stream_worker.py"
+    script.write_text(_STREAM_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29537", str(script), ROOT],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "STREAM OK 2" in out.stdout
