@@ -227,7 +227,7 @@ def stream_main(args, rank, world, dev):
     print(json.dumps({
         "metric": "hand-frames/sec (4-view)", "value": 2 * args.stream_frames * args.steps / elapsed, "unit": "hand-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "fp32x3": "f32 (3 x bf16 split operands, f32 accumulate)"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[4]: synthetic stream of {args.stream_frames} frames x 2 hands x 2 views, produced "
                                f"on the device in chunks of {args.frames} frames, sharded by contiguous chunk over {world} GPU(s), "
@@ -246,8 +246,11 @@ def main():
     ap.add_argument("--frames-per-recording", type=int, default=64)
     ap.add_argument("--chunk-frames", type=int, default=4096)
     ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--precision", choices=("fp32", "bf16"), default="fp32",
-                    help="backbone arithmetic; fp32 is the reference's and the headline line, bf16 is a separate mode")
+    ap.add_argument("--precision", choices=("fp32", "bf16", "fp32x3"), default="fp32",
+                    help="backbone arithmetic; fp32 (fp32 matrix instructions, an fmaf chain per output) is the reference's and the "
+                         "headline line; bf16 is a separate reduced-precision mode; fp32x3 keeps fp32 tensors and multiplies "
+                         "three-way bf16 splits of the operands on the bf16 matrix pipe (fp32-level accuracy, reported separately)")
+    ap.add_argument("--no-x3", action="store_true", help="skip the fp32x3 side measurement of the default fp32 run")
     ap.add_argument("--host-crop-cameras", action="store_true",
                     help="use crop cameras precomputed on the host instead of generating them on the GPU each step")
     ap.add_argument("--stream-frames", type=int, default=0,
@@ -288,11 +291,37 @@ def main():
     elapsed = udist.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
     bb_ms, fwd_ms, calls = pipe.model.timing_read()
     pipe.model.timing_enable(False)
+    fin = mu.finalize_partials(pipe.partials)
+    parity_pred = pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy()   # throughput-mode landmarks
+
+    # side measurement (rank 0's GPU only, no collective in it): the same step with the stride-1 3x3 backbone layers on
+    # the bf16 matrix pipe through three-way operand splitting.  fp32 tensors, fp32-level accuracy; never `value`.
+    x3 = None
+    if args.precision == "fp32" and not args.no_x3 and world == 1:
+        pred32 = pipe.pred_lm.clone()
+        pipe.model.precision = "fp32x3"
+        pipe.step()
+        torch.cuda.synchronize()
+        pipe.model.timing_enable(True)
+        tx = time.perf_counter()
+        for _ in range(2):
+            pipe.step()
+        torch.cuda.synchronize()
+        x3_dt = (time.perf_counter() - tx) / 2
+        x3_bb_ms, _, x3_calls = pipe.model.timing_read()
+        pipe.model.timing_enable(False)
+        pipe.model.precision = "fp32"
+        x3_pred = pipe.pred_lm.view(-1, 21, 3)
+        x3 = {"value": pipe.S / x3_dt, "unit": "hand-frames/s", "ms_per_step": x3_dt * 1e3,
+              "backbone_tflops": BACKBONE_FLOP_PER_CROP * 2 * pipe.chunk / (x3_bb_ms / x3_calls * 1e-3) / 1e12,
+              "max_landmark_diff_vs_fp32_mm": float((pipe.pred_lm - pred32).abs().max()),
+              "x3_pred": x3_pred[:max(args.cpu_hands, 1)].cpu().numpy(),
+              "note": "UMT_PREC_FP32_BF16X3: fp32 tensors; each fp32 operand of the stride-1 3x3 backbone layers is the exact "
+                      "sum of three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulation; 2 timed steps"}
 
     # second mode of section 8(d): the same batch as 64-frame recordings in lock-step with the temporal
     # memory ON (bulk backbone, then T sequential memory+regressor steps); per-rank, no collective
     from umetrack_amd import bulk
-    parity_pred = pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy()   # throughput-mode landmarks
     runner = bulk.BulkSequenceRunner(pipe.model, pipe.wl.n_rec, pipe.wl.T, chunk_samples=pipe.chunk)
     rec_valid = pipe.valid.view(-1, pipe.wl.T)
 
@@ -312,7 +341,6 @@ def main():
     rec_fin = mu.finalize_partials(rec_partials)
 
     hands_per_step = pipe.S * world
-    fin = mu.finalize_partials(pipe.partials)
     if rank != 0:
         return
     crops_per_call = 2 * pipe.chunk
@@ -327,12 +355,15 @@ def main():
             traffic = (tj["read_bytes_per_crop"] + tj["write_bytes_per_crop"]) * crops_per_call
     achieved = BACKBONE_FLOP_PER_CROP * crops_per_call / (bb_ms / calls * 1e-3) / 1e12
     peak = BF16_MATRIX_PEAK_TFLOPS if bf16 else FP32_MATRIX_PEAK_TFLOPS
+    if args.precision == "fp32x3":       # six bf16 matrix instructions per fp32 product
+        peak = BF16_MATRIX_PEAK_TFLOPS / 6
     act_bytes = backbone_activation_bytes_per_crop(2 if bf16 else 4) * crops_per_call
     hbm_achieved = act_bytes / (bb_ms / calls * 1e-3) / 1e9
     line = {
         "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "fp32": "f32", "fp32x3": "f32 (3 x bf16 split operands, f32 accumulate)"}[args.precision],
+        "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[2]: synthetic 4-view x 2-hand batch, {args.frames} frames per GPU, "
                                f"2 crops per hand, {args.precision} MFMA backbone, known-skeleton head, use_memory=False",
                    "frames_per_gpu": args.frames, "hand_frames_per_gpu": pipe.S, "crops_per_gpu": 2 * pipe.S,
@@ -370,6 +401,11 @@ def main():
         line["cpu_baseline"] = base
         n = cpu_pred.shape[0]
         line["parity_sample_max_mm"] = float(np.abs(parity_pred[:n] - cpu_pred).max())
+        if x3 is not None:
+            x3["parity_sample_max_mm"] = float(np.abs(x3["x3_pred"][:n] - cpu_pred).max())
+    if x3 is not None:
+        x3.pop("x3_pred")
+        line["fp32_bf16x3"] = x3
     print(json.dumps(line))
 
 

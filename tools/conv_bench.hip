@@ -3,6 +3,7 @@
 #include "../umetrack_amd/csrc/conv_igemm.hip"
 #include "../umetrack_amd/csrc/conv_bf16.hip"
 #include "../umetrack_amd/csrc/conv_thin.hip"
+#include "../umetrack_amd/csrc/conv_x3.hip"
 #include <vector>
 #include <stdio.h>
 #include <string.h>
@@ -27,6 +28,79 @@ int main(int argc, char** argv) {
                           {32, 64, 48, 9, 2, 0}, {64, 128, 24, 9, 2, 0}, {128, 256, 12, 9, 2, 0}, {32, 64, 48, 1, 2, 0},
                           {128, 256, 12, 1, 2, 0}};
   const int only = argc > 3 ? atoi(argv[3]) : -1;      // index into shapes[], -1 = all
+
+  // fp32 by three-way bf16 splitting (conv_x3.hip) vs the fp32 MFMA kernel, same weights and inputs
+  if (!strcmp(which, "x3")) {
+    const int cfgs[4][3] = {{32, 32, 48}, {64, 64, 24}, {128, 128, 12}, {256, 256, 6}};
+    for (auto& cf : cfgs) {
+      for (int withres = 0; withres < 2; ++withres) {
+      const int cin = cf[0], cout = cf[1], hw = cf[2];
+      ConvLayer L;
+      L.taps = 9; L.cin = cin; L.cout = cout; L.cin_s = cin; L.cout_s = cout; L.cout_w = cout; L.stride = 1; L.relu = 1;
+      const size_t in_n = (size_t)n * hw * hw * cin, out_n = (size_t)n * hw * hw * cout, w_n = (size_t)9 * cin * cout;
+      float *in, *o1, *o2, *res, *w, *vec; uint16_t* w3;
+      hipMalloc(&in, in_n * 4); hipMalloc(&o1, out_n * 4); hipMalloc(&o2, out_n * 4); hipMalloc(&res, out_n * 4);
+      hipMalloc(&w, w_n * 4); hipMalloc(&w3, w_n * 6); hipMalloc(&vec, 3 * cout * 4);
+      std::vector<float> h(in_n > w_n ? in_n : w_n);
+      unsigned s = 4242;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffffff) / 16777216.0f - 0.45f; }
+      hipMemcpy(in, h.data(), in_n * 4, hipMemcpyHostToDevice);
+      hipMemcpy(res, h.data() + 17, (out_n < h.size() - 17 ? out_n : h.size() - 17) * 4, hipMemcpyHostToDevice);
+      // logical weights W[tap][ci][co] (scaled like a trained layer) -> both packings
+      std::vector<float> wl(w_n), wp(w_n);
+      for (size_t i = 0; i < w_n; ++i) wl[i] = h[i + 5] * 0.1f;
+      std::vector<uint16_t> wp3(w_n * 3);
+      auto rne = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+      auto up = [](uint16_t b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
+      for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) {
+            const float v = wl[((size_t)tap * cin + ci) * cout + co];
+            wp[((((size_t)tap * (cin / 8) + ci / 8) * 2 + (ci % 8) / 4) * cout + co) * 4 + ci % 4] = v;
+            float r = v;
+            for (int pl = 0; pl < 3; ++pl) {
+              const uint16_t b = rne(r);
+              r -= up(b);
+              wp3[(((((size_t)tap * (cin / 16) + ci / 16) * 3 + pl) * 2 + (ci % 16) / 8) * cout + co) * 8 + ci % 8] = b;
+            }
+          }
+      hipMemcpy(w, wp.data(), w_n * 4, hipMemcpyHostToDevice);
+      hipMemcpy(w3, wp3.data(), w_n * 6, hipMemcpyHostToDevice);
+      std::vector<float> v3(3 * cout, 0.f);
+      for (int i = 0; i < cout; ++i) { v3[i] = 0.01f * (i % 7); v3[cout + i] = 1.f + 0.01f * (i % 5); v3[2 * cout + i] = -0.02f * (i % 3); }
+      hipMemcpy(vec, v3.data(), v3.size() * 4, hipMemcpyHostToDevice);
+      L.w = w; L.wx3 = w3; L.bias = vec; L.scale = vec + cout; L.shift = vec + 2 * cout;
+      const float* rp = withres ? res : nullptr;
+      launch_conv(L, in, n, hw, hw, rp, o1, 0);
+      hipMemset(o2, 0xff, out_n * 4);
+      if (launch_conv_x3(L, in, n, hw, hw, rp, o2, 0)) return 1;
+      if (hipDeviceSynchronize() != hipSuccess) { printf("x3 kernel failed\n"); return 1; }
+      const size_t chk = out_n < ((size_t)1 << 24) ? out_n : ((size_t)1 << 24);
+      std::vector<float> a(chk), b(chk);
+      hipMemcpy(a.data(), o1, chk * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o2, chk * 4, hipMemcpyDeviceToHost);
+      // tail of the tensor too (partial tiles)
+      std::vector<float> at(4096), bt(4096);
+      hipMemcpy(at.data(), o1 + out_n - 4096, 4096 * 4, hipMemcpyDeviceToHost); hipMemcpy(bt.data(), o2 + out_n - 4096, 4096 * 4, hipMemcpyDeviceToHost);
+      double e = 0, mx = 0, se = 0, sa = 0;
+      for (size_t i = 0; i < chk; ++i) { const double d = (double)a[i] - b[i]; e = fmax(e, fabs(d)); mx = fmax(mx, fabs((double)a[i])); se += d * d; sa += (double)a[i] * a[i]; }
+      for (size_t i = 0; i < 4096; ++i) e = fmax(e, fabs((double)at[i] - bt[i]));
+      hipEvent_t e0, e1v; hipEventCreate(&e0); hipEventCreate(&e1v);
+      float ms_f, ms_x;
+      for (int i = 0; i < 2; ++i) launch_conv_x3(L, in, n, hw, hw, rp, o2, 0);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) launch_conv(L, in, n, hw, hw, rp, o1, 0);
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_f, e0, e1v);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) launch_conv_x3(L, in, n, hw, hw, rp, o2, 0);
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_x, e0, e1v);
+      const double fl = 2.0 * cin * cout * 9 * hw * hw * n;
+      printf("x3 %3d->%3d hw %2d res %d: max|diff| %.3g rms rel %.3g (max|x| %.3g); fp32 %.1f us (%.1f TF), x3 %.1f us (%.1f TF)\n",
+             cin, cout, hw, withres, e, sqrt(se / sa), mx, ms_f / 5 * 1e3, fl / (ms_f / 5) / 1e9, ms_x / 5 * 1e3, fl / (ms_x / 5) / 1e9);
+      hipFree(in); hipFree(o1); hipFree(o2); hipFree(res); hipFree(w); hipFree(w3); hipFree(vec);
+      }
+    }
+    return 0;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     const bool bf = pass == 1;
     if (!bf && !strcmp(which, "bf16")) continue;

@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
 
-PREC_FP32, PREC_BF16 = 0, 1
+PREC_FP32, PREC_BF16, PREC_FP32_BF16X3 = 0, 1, 2
 HEAD_KNOWN_SKELETON, HEAD_PREDICT_SCALE = 0, 1
 WARP_CV2_FIXED_POINT, WARP_FLOAT, WARP_CV2_FIXED_POINT_F64 = 0, 1, 2
 METRIC_WORDS = 108

@@ -14,6 +14,7 @@
 // weights use the same order.  fp32 MFMA is an exact k-ordered fmaf chain, so the
 // result differs from the reference's CPU convolution only by summation order.
 #include "umt_internal.h"
+#include "conv_f32_common.h"
 #include <stdlib.h>
 
 // experiment switches for tools/conv_bench.hip (all off in the library build)
@@ -43,107 +44,6 @@
 
 namespace umt {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct ConvArgs {
-  const float* in;
-  const float* w;
-  const float* bias;
-  const float* scale;
-  const float* shift;
-  const float* residual;
-  float* out;
-  int H, W, Ho, Wo;
-  int cin_s, cout_s, cout_w;
-  int stride, taps, relu;
-  int M;  // n * Ho * Wo output pixels
-  unsigned mg_hw, mg_w;   // floor(2^32 / (H*W)) + 1 and floor(2^32 / W) + 1 (division by multiplication)
-};
-
-// floor(m / d) for 0 <= m < 2^31 and 1 <= d <= 65536 with mg = floor(2^32 / d) + 1: the estimate is exact or one too high
-__device__ __forceinline__ int div_magic32(int m, int d, unsigned mg) {
-  int q = (int)__umulhi((unsigned)m, mg);
-  if (q * d > m) --q;
-  return q;
-}
-
-constexpr int KC = 32;        // input channels staged per step
-constexpr int LDA = KC + 4;   // padded A row (floats): 16 consecutive pixels hit 16 distinct 16-B slots
-
-
-// Epilogue shared by both kernels.  An accumulator tile has its 32 output channels on the lanes,
-// so storing it directly costs sixteen 4-byte-per-lane instructions per tile (and as many loads
-// for the residual).  Instead each wave transposes the tile through its private 32x36-float LDS
-// patch and then moves whole 128-B rows with 16 bytes per lane: conv bias -> BN scale/shift ->
-// residual -> ReLU are applied on float4s.  Caller guarantees all waves are past their last LDS read.
-// PRE (kernel instances launched for layers WITH a residual): the residual rows of all the wave's
-// tiles are requested before the first transpose, so a workgroup exposes one memory latency, not one
-// per tile (the residual is the block input, long evicted from L2 when conv2 ends).
-template <bool PRE>
-__device__ __forceinline__ void store_tile(const f32x16& acc, const float4 (&res)[4], float* patch, int lane, int mbase,
-                                           int cobase, const ConvArgs& a) {
-  const int li = lane & 31, lh = lane >> 5;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDA + li] = acc[r];
-  __builtin_amdgcn_wave_barrier();
-  const int q = lane & 7, rsub = lane >> 3;
-  const int co = cobase + 4 * q;
-  if (co < a.cout_s) {
-    const float4 cb = *reinterpret_cast<const float4*>(a.bias + co);
-    const float4 cs = *reinterpret_cast<const float4*>(a.scale + co);
-    const float4 ch = *reinterpret_cast<const float4*>(a.shift + co);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = 8 * k + rsub;
-      const int m = mbase + row;
-      if (m < a.M) {
-        float4 v = *reinterpret_cast<const float4*>(patch + row * LDA + 4 * q);
-        const size_t o = (size_t)m * a.cout_s + co;
-        v.x = (v.x + cb.x) * cs.x + ch.x;
-        v.y = (v.y + cb.y) * cs.y + ch.y;
-        v.z = (v.z + cb.z) * cs.z + ch.z;
-        v.w = (v.w + cb.w) * cs.w + ch.w;
-        if (PRE || a.residual) {
-          const float4 rr = PRE ? res[k] : *reinterpret_cast<const float4*>(a.residual + o);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        if (a.relu) {      // max(v, 0) as one integer max on the bits (negative floats are negative integers; -0 -> +0)
-          v.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.x), 0));
-          v.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.y), 0));
-          v.z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.z), 0));
-          v.w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.w), 0));
-        }
-        if (!UMT_X_NOSTORE || v.x == 123.456f) *reinterpret_cast<float4*>(a.out + o) = v;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <int TM, int TN, bool PRE>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], float* patch, int lane, int mwave, int cowave,
-                                         const ConvArgs& a) {
-  float4 res[TN][TM][4];
-  if (PRE) {
-    const int q = lane & 7, rsub = lane >> 3;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int m = mwave + i * 32 + 8 * k + rsub;
-          const int co = cowave + j * 32 + 4 * q;
-          res[j][i][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m < a.M && co < a.cout_s) res[j][i][k] = *reinterpret_cast<const float4*>(a.residual + (size_t)m * a.cout_s + co);
-        }
-  }
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-      store_tile<PRE>(acc[i][j], res[j][i], patch, lane, mwave + i * 32, cowave + j * 32, a);
-}
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {

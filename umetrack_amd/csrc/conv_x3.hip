@@ -1,0 +1,268 @@
+// fp32 convolutions on the bf16 matrix pipe by operand splitting (UMT_PREC_FP32_BF16X3).
+//
+// An fp32 number is the exact sum of three bf16 numbers, x = x0 + x1 + x2 with x0 = bf16(x),
+// x1 = bf16(x - x0), x2 = bf16(x - x0 - x1) (round to nearest even; the two subtractions are exact and
+// |x1| <= 2^-8 |x|, |x2| <= 2^-16 |x|).  A product a*b is then the sum of nine bf16 x bf16 products, each
+// exact in fp32; the kernel keeps the six largest,
+//     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// and drops a1 b2 + a2 b1 + a2 b2 <= 2^-23 |a b| - below the 2^-24-of-the-running-sum rounding every
+// fp32 accumulation step makes anyway.  The sums run in the fp32 accumulators of
+// v_mfma_f32_32x32x16_bf16, whose rate is 16x that of v_mfma_f32_32x32x2_f32: six of them per fp32
+// product leave 2.67x the fp32 pipe's arithmetic rate.  Results are NOT bit-identical to the fmaf-chain
+// kernel (conv_igemm.hip), they agree with it to fp32 rounding noise; tests/test_gpu_x3.py states the bound.
+//
+// Interface and structure are those of conv3x3s1_halo_f32: fp32 channels-last rows in and out, fp32
+// epilogue (conv bias -> BN -> residual -> ReLU), one flattened halo range of pixel rows staged per
+// 32-channel chunk, weights streamed from L2 in fragment order.  The activations are split ONCE, when a
+// row is written to LDS (three bf16 planes per row), not per operand fetch: a staged element feeds 9 taps
+// x cout/32 fragments.  The weights are split on the host at umt_model_finalize:
+//     packed[tap][cin/16][plane][h][cout_w][8].
+#include "umt_internal.h"
+#include "conv_f32_common.h"
+#include <stdlib.h>
+
+#ifndef UMT_X3_PIPE
+#define UMT_X3_PIPE 1
+#endif
+#ifndef UMT_X3_CFG64
+#define UMT_X3_CFG64 2, 2, 2, 1
+#endif
+#ifndef UMT_X3_CFG32
+#define UMT_X3_CFG32 4, 1, 1, 1
+#endif
+
+namespace umt {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int X3_PLANE = 80;            // bytes of one plane of a row: 32 bf16 + 8 pad
+constexpr int X3_ROW = 3 * X3_PLANE;    // 240 B = 15 sixteen-byte slots: 16 consecutive rows hit 16 distinct slots
+
+// two fp32 -> their packed bf16 roundings, and the exact remainders
+__device__ __forceinline__ unsigned x3_split2(float& a, float& b) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 v = {a, b};
+  const unsigned p = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  a -= __builtin_bit_cast(float, p << 16);
+  b -= __builtin_bit_cast(float, p & 0xffff0000u);
+  return p;
+}
+
+// float4 -> three planes of 4 bf16 (8 bytes each)
+__device__ __forceinline__ void x3_split4(float4 v, uint2& p0, uint2& p1, uint2& p2) {
+  p0.x = x3_split2(v.x, v.y); p0.y = x3_split2(v.z, v.w);
+  p1.x = x3_split2(v.x, v.y); p1.y = x3_split2(v.z, v.w);
+  p2.x = x3_split2(v.x, v.y); p2.y = x3_split2(v.z, v.w);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
+__global__ __launch_bounds__(256, 2) void conv3x3s1_halo_x3(ConvArgs a) {
+  constexpr int BM = WAVES_M * TM * 32;
+  constexpr int BN = WAVES_N * TN * 32;
+  static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");
+  extern __shared__ __attribute__((aligned(16))) unsigned char sX[];   // (BM + 2W + 2) rows x 240 B + one zero row
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  int tile_m, tile_n;
+  xcd_tile(tile_m, tile_n);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int g0 = m0 - W - 1;
+  const int c16_total = a.cin_s >> 4;
+  const int nchunks = (a.cin_s + KC - 1) / KC;
+
+  // byte offset of the lane's operand row per tap (the all-zero row where the neighbour does not exist)
+  int arow[TM][9];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + (wm * TM + i) * 32 + li;
+    const bool live = m < a.M;
+    const int mm = live ? m : 0;
+    const int rem = mm - div_magic32(mm, H * W, a.mg_hw) * (H * W);
+    const int y = div_magic32(rem, W, a.mg_w), x = rem - y * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        arow[i][ky * 3 + kx] = (ok ? (wm * TM + i) * 32 + li + ky * W + kx : rows) * X3_ROW + 16 * lh;
+      }
+  }
+  if (tid < X3_ROW / 16) *reinterpret_cast<uint4*>(sX + rows * X3_ROW + 16 * tid) = make_uint4(0, 0, 0, 0);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // B fragments: buffer loads with a scalar (tap, channel group, plane) offset and one 32-bit lane offset.
+  // A k-step is one 16-channel group of one tap (18 per chunk); its 3 x TN fragments are requested two
+  // k-steps (2 x 6 TM TN MFMAs) ahead into a ring of three slots - 18 % 3 == 0, so a slot index is static.
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const int w_plane = 2 * a.cout_w * 16;                  // bytes per (tap, group, plane)
+  const int wvoff = (n0 + lh * a.cout_w + wn * TN * 32 + li) * 16;
+#if UMT_X3_PIPE
+  // two slots: the fragments of k-step ks+1 (B from L2, A from LDS) are requested before the MFMAs of ks
+  uint4 bring[2][3][TN];
+#else
+  uint4 bring[3][3][TN];
+#endif
+  auto load_b = [&](uint4 (&dst)[3][TN], int tap, int c16) {
+    const int g = min(c16, c16_total - 1);                // a group past the end meets zero-filled A
+    const int soff = (tap * c16_total + g) * 3 * w_plane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + j * 512, soff + p * w_plane, 0);
+        dst[p][j] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+  };
+  load_b(bring[0], 0, 0);
+#if !UMT_X3_PIPE
+  load_b(bring[1], 0, 1);
+#endif
+
+  // A staging as in conv3x3s1_halo_f32 (thread t owns slots t + 256 k: row idx>>3, channel quad idx&7); the
+  // next chunk's range is fetched into registers while this chunk's MFMAs run
+  constexpr int NLD = (BM + 2 * 48 + 2 + 31) / 32;     // W <= 48
+  float4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * KC;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 3, q = idx & 7;
+      const int g = g0 + r;
+      const bool ok = r < rows && g >= 0 && g < a.M && (c0 + 4 * q) < a.cin_s;
+      const size_t off = ok ? (size_t)g * a.cin_s + c0 + 4 * q : 0;
+      areg[k] = *reinterpret_cast<const float4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  load_a(0);
+
+  auto read_a = [&](bf16x8 (&dst)[TM][3], int tap, int c) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        dst[i][p] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sX + arow[i][tap] + p * X3_PLANE + c * 32));
+  };
+  // the six products of one k-step, smallest terms first: plane pairs (pa, pb) with pa + pb = 2, 1, 0
+  auto mfma6 = [&](const bf16x8 (&av)[TM][3], const uint4 (&b)[3][TN]) {
+#pragma unroll
+    for (int s = 2; s >= 0; --s)
+#pragma unroll
+      for (int pa = 0; pa <= s; ++pa)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][pa], __builtin_bit_cast(bf16x8, b[s - pa][j]), acc[i][j], 0, 0, 0);
+  };
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      float4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((idx >> 3) < rows) {
+        uint2 p0, p1, p2;
+        x3_split4(v, p0, p1, p2);
+        unsigned char* d = sX + (idx >> 3) * X3_ROW + 8 * (idx & 7);
+        *reinterpret_cast<uint2*>(d) = p0;
+        *reinterpret_cast<uint2*>(d + X3_PLANE) = p1;
+        *reinterpret_cast<uint2*>(d + 2 * X3_PLANE) = p2;
+      }
+    }
+    __syncthreads();
+#if UMT_X3_PIPE
+    bf16x8 av[2][TM][3];
+    read_a(av[0], 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+      if (ks < 17) load_b(bring[(ks + 1) & 1], (ks + 1) >> 1, chunk * 2 + ((ks + 1) & 1));
+      else if (chunk + 1 < nchunks) load_b(bring[0], 0, (chunk + 1) * 2);
+      if (ks < 17) read_a(av[(ks + 1) & 1], (ks + 1) >> 1, (ks + 1) & 1);
+      if (ks == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma6(av[ks & 1], bring[ks & 1]);
+    }
+#else
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+      const int tap = ks >> 1, c = ks & 1;
+      if (ks < 16) load_b(bring[(ks + 2) % 3], (ks + 2) >> 1, chunk * 2 + (ks & 1));
+      else if (chunk + 1 < nchunks) load_b(bring[(ks + 2) % 3], 0, (chunk + 1) * 2 + (ks & 1));
+      if (ks == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 av[TM][3];
+      read_a(av, tap, c);
+      mfma6(av, bring[ks % 3]);
+    }
+#endif
+    __syncthreads();
+  }
+
+  float* patch = reinterpret_cast<float*>(sX) + wave * 32 * LDA;
+  epilogue<TM, TN, RES>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static void launch_halo_x3(const ConvArgs& a, hipStream_t stream) {
+  constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+  dim3 grid((a.M + BM - 1) / BM, a.cout_w / BN);
+  size_t lds = (size_t)(BM + 2 * a.W + 2 + 1) * X3_ROW;
+  const size_t patch = (size_t)4 * 32 * LDA * sizeof(float);
+  if (lds < patch) lds = patch;
+  void (*kern)(ConvArgs) = a.residual ? conv3x3s1_halo_x3<WAVES_M, WAVES_N, TM, TN, true>
+                                      : conv3x3s1_halo_x3<WAVES_M, WAVES_N, TM, TN, false>;
+  if (lds > 65536) {
+    static unsigned char done[2][64];
+    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256, done[a.residual ? 1 : 0])) return;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+}
+
+bool conv_x3_applicable(const ConvLayer& L, int w) {
+  return L.wx3 && L.taps == 9 && L.stride == 1 && w <= 48 && L.cin_s % 16 == 0 &&
+         (L.cout_w == 32 || L.cout_w == 64 || L.cout_w % 128 == 0);
+}
+
+int launch_conv_x3(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
+                   hipStream_t stream) {
+  UMT_REQUIRE(conv_x3_applicable(L, w), UMT_ERR_INVALID, "conv_x3: layer not supported (taps %d stride %d w %d cout %d)",
+              L.taps, L.stride, w, L.cout_w);
+  UMT_REQUIRE(L.cout_s % 8 == 0 && L.cout_s <= L.cout_w && n > 0 && h > 0, UMT_ERR_INVALID, "conv_x3: bad shapes");
+  ConvArgs a;
+  a.in = in; a.w = reinterpret_cast<const float*>(L.wx3); a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
+  a.residual = residual; a.out = out;
+  a.H = h; a.W = w; a.Ho = h; a.Wo = w;
+  a.cin_s = L.cin_s; a.cout_s = L.cout_s; a.cout_w = L.cout_w;
+  a.stride = 1; a.taps = 9; a.relu = L.relu;
+  const int64_t M = (int64_t)n * h * w;
+  UMT_REQUIRE(M < (int64_t)1 << 31, UMT_ERR_INVALID, "conv_x3: too many pixels");
+  a.M = (int)M;
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
+  if (L.cout_w % 128 == 0) launch_halo_x3<2, 2, 2, 2>(a, stream);
+  else if (L.cout_w == 64) launch_halo_x3<UMT_X3_CFG64>(a, stream);
+  else launch_halo_x3<UMT_X3_CFG32>(a, stream);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace umt

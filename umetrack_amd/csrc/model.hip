@@ -245,6 +245,34 @@ static void pack_conv_bf16(const umt_model* m, std::vector<uint16_t>& host, std:
   packed.push_back(p);
 }
 
+// Three-way bf16 split of one 3x3 conv's fp32 weights for conv_x3.hip (w = w0 + w1 + w2 exactly):
+//   packed[tap][g][plane][h][co][j] = plane-th piece of W[co][ci = 16*g + 8*h + j][ky][kx]
+static float from_bf16(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static void pack_conv_x3(const umt_model* m, std::vector<uint16_t>& host, std::vector<PackedH>& packed, ConvLayer* L,
+                         const std::string& wkey) {
+  const std::vector<float>& w = val(m, wkey);
+  const int c16 = L->cin_s / 16;
+  PackedH p{L, host.size()};
+  host.resize(host.size() + (size_t)L->taps * c16 * 3 * 2 * L->cout_w * 8, 0);
+  uint16_t* dst = host.data() + p.off;
+  for (int tap = 0; tap < L->taps; ++tap)
+    for (int ci = 0; ci < L->cin; ++ci)
+      for (int co = 0; co < L->cout; ++co) {
+        float r = w[((size_t)co * L->cin + ci) * L->taps + tap];
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint16_t b = to_bf16(r);
+          r -= from_bf16(b);       // exact
+          dst[(((((size_t)tap * c16 + ci / 16) * 3 + pl) * 2 + (ci % 16) / 8) * L->cout_w + co) * 8 + ci % 8] = b;
+        }
+      }
+  packed.push_back(p);
+}
+
 static void pack_block(const umt_model* m, std::vector<float>& host, std::vector<Packed>& packed, BlockLayers* B,
                        const std::string& p, int stride, bool down) {
   pack_conv(m, host, packed, &B->conv1, p + ".conv1.weight", "", p + ".bn1", stride, 1);
@@ -321,7 +349,13 @@ static int check_ready(const umt_model* m) {
 // ---- stages on channels-last rows ----
 // Blocks [b0, b1) on n crops whose rows start at x; returns the buffer that holds the result.
 // x/t/y rotate; the down-sample branch goes to d.
-static int run_blocks(umt_model* m, size_t b0, size_t b1, int n, float*& x, float*& t, float*& y, float* d,
+// x3: stride-1 3x3 layers on the bf16 matrix pipe with three-way split operands (conv_x3.hip); every tensor stays fp32.
+static int conv_f32(const ConvLayer& L, bool x3, const float* in, int n, int hw, const float* res, float* out, hipStream_t s) {
+  if (x3 && conv_x3_applicable(L, hw)) return launch_conv_x3(L, in, n, hw, hw, res, out, s);
+  return launch_conv(L, in, n, hw, hw, res, out, s);
+}
+
+static int run_blocks(umt_model* m, bool x3, size_t b0, size_t b1, int n, float*& x, float*& t, float*& y, float* d,
                       hipStream_t s) {
   for (size_t i = b0; i < b1; ++i) {
     const BlockLayers& B = m->blocks[i];
@@ -331,14 +365,14 @@ static int run_blocks(umt_model* m, size_t b0, size_t b1, int n, float*& x, floa
       UMT_TRY(launch_conv_s2_fused(B.conv1, &B.down, x, n, hw, hw, t, d, s));     // conv1 and the down-sample branch
       res = d;
     } else {
-      UMT_TRY(launch_conv(B.conv1, x, n, hw, hw, nullptr, t, s));
+      UMT_TRY(conv_f32(B.conv1, x3, x, n, hw, nullptr, t, s));
       if (B.has_down) {
         UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, d, s));
         res = d;
       }
     }
     const int hw2 = hw / B.conv1.stride;
-    UMT_TRY(launch_conv(B.conv2, t, n, hw2, hw2, res, y, s));
+    UMT_TRY(conv_f32(B.conv2, x3, t, n, hw2, res, y, s));
     float* old = x;
     x = y;
     y = old;
@@ -351,7 +385,7 @@ static int stage1_sub() {
   return v;
 }
 
-static int backbone_rows(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
+static int backbone_rows(umt_model* m, bool x3, const float* images, int n, const BackboneWs& w, hipStream_t s) {
   float *x = w.a, *t = w.b, *y = w.c;
   const int sub = stage1_sub();
   size_t first = 0;
@@ -366,7 +400,7 @@ static int backbone_rows(umt_model* m, const float* images, int n, const Backbon
       const size_t off = (size_t)c0 * ACT_FLOATS;
       float *xs = w.a + off, *ts = w.b + off, *ys = w.c + off;
       UMT_TRY(launch_stem(m->stem, images + (size_t)c0 * 96 * 96, nc, xs, s));
-      UMT_TRY(run_blocks(m, 0, nb1, nc, xs, ts, ys, w.d, s));
+      UMT_TRY(run_blocks(m, x3, 0, nb1, nc, xs, ts, ys, w.d, s));
       xe = xs - off; te = ts - off; ye = ys - off;    // same rotation for every group
     }
     x = xe; t = te; y = ye;
@@ -374,7 +408,7 @@ static int backbone_rows(umt_model* m, const float* images, int n, const Backbon
   } else {
     UMT_TRY(launch_stem(m->stem, images, n, x, s));
   }
-  UMT_TRY(run_blocks(m, first, m->blocks.size(), n, x, t, y, w.d, s));
+  UMT_TRY(run_blocks(m, x3, first, m->blocks.size(), n, x, t, y, w.d, s));
   UMT_TRY(launch_conv(m->proj, x, n, 6, 6, nullptr, w.feat, s));
   return 0;
 }
@@ -432,7 +466,8 @@ static int backbone_rows_bf16(umt_model* m, const float* images, int n, const Ba
 }
 
 static int backbone_any(umt_model* m, int precision, const float* images, int n, const BackboneWs& w, hipStream_t s) {
-  return precision == UMT_PREC_BF16 ? backbone_rows_bf16(m, images, n, w, s) : backbone_rows(m, images, n, w, s);
+  if (precision == UMT_PREC_BF16) return backbone_rows_bf16(m, images, n, w, s);
+  return backbone_rows(m, precision == UMT_PREC_FP32_BF16X3, images, n, w, s);
 }
 
 // feat rows [n*36][72] -> fused features written into tin channels 18..89
@@ -627,6 +662,17 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
       }
     pack_conv_bf16(m, host_h, packed_h, &m->proj, bb + ".1.weight");
   }
+  std::vector<PackedH> packed_x3;     // same slab, after the bf16 copies
+  {
+    int bi = 0;
+    for (int s = 0; s < 4; ++s)
+      for (int b = 0; b < N_STAGE_BLOCKS[s]; ++b, ++bi) {
+        const std::string p = bb + ".0._layers." + std::to_string(s + 1) + "." + std::to_string(b);
+        BlockLayers& B = m->blocks[bi];
+        if (B.conv1.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.conv1, p + ".conv1.weight");
+        if (B.conv2.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.conv2, p + ".conv2.weight");
+      }
+  }
   const std::string fu = "_feature_extractor._multi_view_fusion";
   pack_conv(m, host, packed, &m->fuse1, fu + ".0.weight", fu + ".0.bias", fu + ".1", 1, 1);
   pack_conv(m, host, packed, &m->fuse2, fu + ".3.weight", fu + ".3.bias", fu + ".4", 1, 1);
@@ -676,6 +722,7 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
   UMT_CHECK_HIP(hipMalloc((void**)&m->slab_h, host_h.size() * sizeof(uint16_t)));
   UMT_CHECK_HIP(hipMemcpy(m->slab_h, host_h.data(), host_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   for (const PackedH& p : packed_h) p.layer->wh = m->slab_h + p.off;   // every size is a multiple of 8 bf16 = 16 B
+  for (const PackedH& p : packed_x3) p.layer->wx3 = m->slab_h + p.off;
   m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3]};
   m->skel = SkelParams{m->slab + sk_off[0], m->slab + sk_off[1], m->slab + sk_off[2], m->slab + sk_off[3]};
   m->device = device;
@@ -762,7 +809,7 @@ static int check_ws(const char* what, void* ws, int64_t have, int64_t need) {
 extern "C" int umt_backbone_forward(umt_model* m, const float* images, int n, int precision, float* features,
                                     void* workspace, int64_t workspace_bytes, void* stream) {
   UMT_TRY(check_ready(m));
-  UMT_REQUIRE(precision == UMT_PREC_FP32 || precision == UMT_PREC_BF16, UMT_ERR_INVALID, "backbone: precision = %d", precision);
+  UMT_REQUIRE(precision >= UMT_PREC_FP32 && precision <= UMT_PREC_FP32_BF16X3, UMT_ERR_INVALID, "backbone: precision = %d", precision);
   UMT_REQUIRE(n > 0 && images && features, UMT_ERR_INVALID, "backbone: n=%d or null pointer", n);
   UMT_TRY(check_ws("backbone", workspace, workspace_bytes, umt_backbone_workspace_bytes(n)));
   Carver cv(workspace, workspace_bytes);
@@ -838,7 +885,7 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
                                  float* wrist_xfs, float* sigmas, float* skel_scales, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
   UMT_TRY(check_ready(m));
-  UMT_REQUIRE(precision == UMT_PREC_FP32 || precision == UMT_PREC_BF16, UMT_ERR_INVALID, "forward: precision = %d", precision);
+  UMT_REQUIRE(precision >= UMT_PREC_FP32 && precision <= UMT_PREC_FP32_BF16X3, UMT_ERR_INVALID, "forward: precision = %d", precision);
   UMT_REQUIRE(head == UMT_HEAD_KNOWN_SKELETON || head == UMT_HEAD_PREDICT_SCALE, UMT_ERR_INVALID, "head = %d", head);
   UMT_REQUIRE(n > 0 && bs > 0 && bs <= n && n <= 2 * bs, UMT_ERR_INVALID, "forward: n=%d crops for bs=%d samples", n, bs);
   UMT_REQUIRE(images && intrinsics && extrinsics && sample_range && memory_idx && use_memory && hand_idx &&

@@ -90,6 +90,7 @@ struct ConvLayer {
   const float* scale = nullptr;  // dev [cout_w]
   const float* shift = nullptr;  // dev [cout_w]
   const uint16_t* wh = nullptr;  // dev, bf16 packed [tap][cin_s/16][2][cout_w][8] (backbone layers only)
+  const uint16_t* wx3 = nullptr; // dev, three-way bf16 split [tap][cin_s/16][plane][2][cout_w][8] (backbone 3x3 layers)
 };
 
 // conv_igemm.hip
@@ -107,6 +108,11 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
 
 int launch_conv_s2_fused_bf16(const ConvLayer& c1, const ConvLayer* ds, const uint16_t* in, int n, int h, int w,
                               uint16_t* out, uint16_t* ds_out, hipStream_t stream);
+
+// conv_x3.hip: fp32 rows in and out, operands split into three bf16 each, six bf16 MFMAs per fp32 product
+bool conv_x3_applicable(const ConvLayer& L, int w);
+int launch_conv_x3(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
+                   hipStream_t stream);
 
 // conv_thin.hip: persistent bf16 kernel for the 32->32 stride-1 3x3 layers (weights in registers)
 extern int g_conv_thin;

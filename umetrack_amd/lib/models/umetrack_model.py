@@ -16,6 +16,9 @@ from ... import _native as nat
 from ... import arch
 from .regressor import RegressorOutput
 
+_PRECISIONS = {"fp32": nat.PREC_FP32, "bf16": nat.PREC_BF16, "fp32x3": nat.PREC_FP32_BF16X3}
+_PRECISIONS_INV = {v: k for k, v in _PRECISIONS.items()}
+
 
 @dataclass
 class InputFrameData:
@@ -112,15 +115,17 @@ class UmeTrackModel:
 
     @property
     def precision(self) -> str:
-        """"fp32" (default, the reference's arithmetic) or "bf16" (bf16 backbone activations and
-        weights with fp32 accumulation; fusion, temporal memory and the head stay fp32)."""
-        return "bf16" if self._precision == nat.PREC_BF16 else "fp32"
+        """"fp32" (default, the reference's arithmetic), "bf16" (bf16 backbone activations and
+        weights with fp32 accumulation; fusion, temporal memory and the head stay fp32) or "fp32x3"
+        (fp32 tensors; the stride-1 3x3 backbone layers multiply three-way bf16 splits of their fp32
+        operands on the bf16 matrix pipe - fp32-level accuracy, not bit-identical to "fp32")."""
+        return _PRECISIONS_INV[self._precision]
 
     @precision.setter
     def precision(self, value: str) -> None:
-        if value not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {value!r}")
-        self._precision = nat.PREC_BF16 if value == "bf16" else nat.PREC_FP32
+        if value not in _PRECISIONS:
+            raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp32x3', got {value!r}")
+        self._precision = _PRECISIONS[value]
 
     def getInputImageSizes(self) -> Tuple[int, int]:
         return (arch.CROP_HW, arch.CROP_HW)
