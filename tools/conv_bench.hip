@@ -29,6 +29,75 @@ int main(int argc, char** argv) {
                           {128, 256, 12, 1, 2, 0}};
   const int only = argc > 3 ? atoi(argv[3]) : -1;      // index into shapes[], -1 = all
 
+
+  // fused stride-2 conv1 + down-sample: split-operand kernel vs the fp32 fused kernel
+  if (!strcmp(which, "x3s2")) {
+    const int cfgs[3][3] = {{32, 64, 48}, {64, 128, 24}, {128, 256, 12}};
+    auto rne = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+    auto up = [](uint16_t b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    auto pack = [&](int taps, int cin, int cout, const float* wl, std::vector<float>& wp, std::vector<uint16_t>& wp3) {
+      wp.assign((size_t)taps * cin * cout, 0.f); wp3.assign((size_t)taps * cin * cout * 3, 0);
+      for (int tap = 0; tap < taps; ++tap)
+        for (int ci = 0; ci < cin; ++ci)
+          for (int co = 0; co < cout; ++co) {
+            const float v = wl[((size_t)tap * cin + ci) * cout + co];
+            wp[((((size_t)tap * (cin / 8) + ci / 8) * 2 + (ci % 8) / 4) * cout + co) * 4 + ci % 4] = v;
+            float r = v;
+            for (int pl = 0; pl < 3; ++pl) {
+              const uint16_t b = rne(r);
+              r -= up(b);
+              wp3[(((((size_t)tap * (cin / 16) + ci / 16) * 3 + pl) * 2 + (ci % 16) / 8) * cout + co) * 8 + ci % 8] = b;
+            }
+          }
+    };
+    for (auto& cf : cfgs) {
+      const int cin = cf[0], cout = cf[1], hw = cf[2], ho = hw / 2;
+      ConvLayer C, D;
+      C.taps = 9; C.cin = cin; C.cout = cout; C.cin_s = cin; C.cout_s = cout; C.cout_w = cout; C.stride = 2; C.relu = 1;
+      D = C; D.taps = 1; D.relu = 0;
+      const size_t in_n = (size_t)n * hw * hw * cin, out_n = (size_t)n * ho * ho * cout, w_n = (size_t)9 * cin * cout, wd_n = (size_t)cin * cout;
+      float *in, *o1, *o2, *d1, *d2, *w, *wd, *vec; uint16_t *w3, *wd3;
+      hipMalloc(&in, in_n * 4); hipMalloc(&o1, out_n * 4); hipMalloc(&o2, out_n * 4); hipMalloc(&d1, out_n * 4); hipMalloc(&d2, out_n * 4);
+      hipMalloc(&w, w_n * 4); hipMalloc(&wd, wd_n * 4); hipMalloc(&w3, w_n * 6); hipMalloc(&wd3, wd_n * 6); hipMalloc(&vec, 3 * cout * 4);
+      std::vector<float> h(in_n > w_n ? in_n : w_n);
+      unsigned s = 999;
+      for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffffff) / 16777216.0f - 0.45f; }
+      hipMemcpy(in, h.data(), in_n * 4, hipMemcpyHostToDevice);
+      std::vector<float> wl(w_n), wdl(wd_n), wp, wdp; std::vector<uint16_t> wp3, wdp3;
+      for (size_t i = 0; i < w_n; ++i) wl[i] = h[i + 5] * 0.1f;
+      for (size_t i = 0; i < wd_n; ++i) wdl[i] = h[i + 77777] * 0.2f;
+      pack(9, cin, cout, wl.data(), wp, wp3); pack(1, cin, cout, wdl.data(), wdp, wdp3);
+      hipMemcpy(w, wp.data(), w_n * 4, hipMemcpyHostToDevice); hipMemcpy(w3, wp3.data(), w_n * 6, hipMemcpyHostToDevice);
+      hipMemcpy(wd, wdp.data(), wd_n * 4, hipMemcpyHostToDevice); hipMemcpy(wd3, wdp3.data(), wd_n * 6, hipMemcpyHostToDevice);
+      std::vector<float> v3(3 * cout, 0.f);
+      for (int i = 0; i < cout; ++i) { v3[i] = 0.01f * (i % 7); v3[cout + i] = 1.f + 0.01f * (i % 5); v3[2 * cout + i] = -0.02f * (i % 3); }
+      hipMemcpy(vec, v3.data(), v3.size() * 4, hipMemcpyHostToDevice);
+      C.w = w; C.wx3 = w3; D.w = wd; D.wx3 = wd3; C.bias = D.bias = vec; C.scale = D.scale = vec + cout; C.shift = D.shift = vec + 2 * cout;
+      if (launch_conv_s2_fused(C, &D, in, n, hw, hw, o1, d1, 0)) return 1;
+      hipMemset(o2, 0xff, out_n * 4); hipMemset(d2, 0xff, out_n * 4);
+      if (launch_conv_s2_fused_x3(C, &D, in, n, hw, hw, o2, d2, 0)) return 1;
+      if (hipDeviceSynchronize() != hipSuccess) { printf("x3s2 kernel failed\n"); return 1; }
+      std::vector<float> a(out_n), b(out_n);
+      double e1 = 0, m1 = 0, e2 = 0, m2 = 0;
+      hipMemcpy(a.data(), o1, out_n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o2, out_n * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < out_n; ++i) { e1 = fmax(e1, fabs((double)a[i] - b[i])); m1 = fmax(m1, fabs((double)a[i])); }
+      hipMemcpy(a.data(), d1, out_n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), d2, out_n * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < out_n; ++i) { e2 = fmax(e2, fabs((double)a[i] - b[i])); m2 = fmax(m2, fabs((double)a[i])); }
+      hipEvent_t e0, e1v; hipEventCreate(&e0); hipEventCreate(&e1v);
+      float ms_f, ms_x;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) launch_conv_s2_fused(C, &D, in, n, hw, hw, o1, d1, 0);
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_f, e0, e1v);
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) launch_conv_s2_fused_x3(C, &D, in, n, hw, hw, o2, d2, 0);
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_x, e0, e1v);
+      const double fl = 2.0 * cin * cout * 10 * ho * ho * n;
+      printf("x3s2 %3d->%3d hw %2d: conv1 max|diff| %.3g (max %.3g), ds max|diff| %.3g (max %.3g); fp32 fused %.1f us (%.1f TF), x3 %.1f us (%.1f TF)\n",
+             cin, cout, hw, e1, m1, e2, m2, ms_f / 5 * 1e3, fl / (ms_f / 5) / 1e9, ms_x / 5 * 1e3, fl / (ms_x / 5) / 1e9);
+      hipFree(in); hipFree(o1); hipFree(o2); hipFree(d1); hipFree(d2); hipFree(w); hipFree(wd); hipFree(w3); hipFree(wd3); hipFree(vec);
+    }
+    return 0;
+  }
   // fp32 by three-way bf16 splitting (conv_x3.hip) vs the fp32 MFMA kernel, same weights and inputs
   if (!strcmp(which, "x3")) {
     const int cfgs[4][3] = {{32, 32, 48}, {64, 64, 24}, {128, 128, 12}, {256, 256, 6}};

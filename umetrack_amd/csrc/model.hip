@@ -361,7 +361,10 @@ static int run_blocks(umt_model* m, bool x3, size_t b0, size_t b1, int n, float*
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
     const float* res = x;
-    if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
+    if (B.has_down && x3 && conv_s2_x3_applicable(B.conv1, &B.down, hw, hw)) {
+      UMT_TRY(launch_conv_s2_fused_x3(B.conv1, &B.down, x, n, hw, hw, t, d, s));
+      res = d;
+    } else if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
       UMT_TRY(launch_conv_s2_fused(B.conv1, &B.down, x, n, hw, hw, t, d, s));     // conv1 and the down-sample branch
       res = d;
     } else {
@@ -671,6 +674,7 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
         BlockLayers& B = m->blocks[bi];
         if (B.conv1.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.conv1, p + ".conv1.weight");
         if (B.conv2.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.conv2, p + ".conv2.weight");
+        if (B.has_down && B.down.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.down, p + ".downsample.0.weight");
       }
   }
   const std::string fu = "_feature_extractor._multi_view_fusion";

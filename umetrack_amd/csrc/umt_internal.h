@@ -114,6 +114,10 @@ bool conv_x3_applicable(const ConvLayer& L, int w);
 int launch_conv_x3(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
                    hipStream_t stream);
 
+bool conv_s2_x3_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w);
+int launch_conv_s2_fused_x3(const ConvLayer& c1, const ConvLayer* ds, const float* in, int n, int h, int w, float* out,
+                            float* ds_out, hipStream_t stream);
+
 // conv_thin.hip: persistent bf16 kernel for the 32->32 stride-1 3x3 layers (weights in registers)
 extern int g_conv_thin;
 bool conv_thin_applicable(const ConvLayer& L, int w);
