@@ -357,6 +357,9 @@ def main():
     peak = BF16_MATRIX_PEAK_TFLOPS if bf16 else FP32_MATRIX_PEAK_TFLOPS
     if args.precision == "fp32x3":       # six bf16 matrix instructions per fp32 product
         peak = BF16_MATRIX_PEAK_TFLOPS / 6
+    peak_note = {"fp32": "fp32 matrix peak (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 dense matrix peak",
+                 "fp32x3": "bf16 dense matrix peak / 6: six v_mfma_f32_32x32x16_bf16 per fp32 product; achieved counts each "
+                           f"fp32 multiply-add once (= {achieved / FP32_MATRIX_PEAK_TFLOPS:.3f} of the fp32 matrix peak)"}[args.precision]
     act_bytes = backbone_activation_bytes_per_crop(2 if bf16 else 4) * crops_per_call
     hbm_achieved = act_bytes / (bb_ms / calls * 1e-3) / 1e9
     line = {
@@ -371,14 +374,15 @@ def main():
                    "chunk_frames": args.chunk_frames, "weights": "seeded random (pretrained_weights.torch not distributed)",
                    "parallelism": f"frames sharded over {world} GPU(s); all-reduce of 108 float64 metric partials"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": traffic,
+                     "frac": achieved / peak, "peak_note": peak_note, "traffic": traffic,
                      "traffic_note": "HBM bytes per forward call from rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
                                      "profiles/r01_backbone_traffic.json (measured at 2048 crops/call, scaled per crop)",
                      "hbm_view": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": hbm_achieved / HBM_PEAK_GBS,
                                   "note": "same launches priced by bytes: unfused input+output(+residual) rows of every "
                                           "backbone launch; the bf16 backbone sits between the two rooflines"},
-                     "kernel": "backbone: stem + 27 " + ("conv_*_bf16" if bf16 else "conv_igemm_f32 / conv3x3s1_halo_f32")
+                     "kernel": "backbone: stem + 24 " + {"bf16": "conv_*_bf16", "fp32": "conv_igemm_f32 / conv3x3s1_halo_f32 / conv3x3s2_ds_f32",
+                                                          "fp32x3": "conv3x3s1_halo_x3 / conv3x3s2_ds_x3 (+ conv3x3s2_ds_f32, conv_igemm_f32)"}[args.precision]
                                + " launches per forward call",
                      "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
                      "forward_avg_ms": fwd_ms / calls, "calls": calls},

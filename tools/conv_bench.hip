@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
 
   // fused stride-2 conv1 + down-sample: split-operand kernel vs the fp32 fused kernel
   if (!strcmp(which, "x3s2")) {
-    const int cfgs[3][3] = {{32, 64, 48}, {64, 128, 24}, {128, 256, 12}};
+    const int cfgs[2][3] = {{64, 128, 24}, {128, 256, 12}};
     auto rne = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
     auto up = [](uint16_t b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
     auto pack = [&](int taps, int cin, int cout, const float* wl, std::vector<float>& wp, std::vector<uint16_t>& wp3) {
@@ -240,7 +240,7 @@ int main(int argc, char** argv) {
   }
   // fused stride-2 conv1 + down-sample vs the two separate launches
   if (strcmp(which, "bf16")) {
-    const int cfgs[3][3] = {{32, 64, 48}, {64, 128, 24}, {128, 256, 12}};
+    const int cfgs[2][3] = {{64, 128, 24}, {128, 256, 12}};
     for (auto& cf : cfgs) {
       const int cin = cf[0], cout = cf[1], hw = cf[2], ho = hw / 2;
       ConvLayer C, D;

@@ -10,13 +10,13 @@ set -e
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/bench -o b --output-format csv -- python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-hands 0 --no-pcie > $OUT/bench_prof.json 2> $OUT/bench_prof.err
 echo "bench under rocprof done"
 # 2. per-layer tables
-for P in fp32 bf16; do
+for P in fp32 bf16 fp32x3; do
   timeout -k 10 200 rocprofv3 --kernel-trace -d $OUT/lt_$P -o t --output-format csv -- python3 $ROOT/tools/profile_forward.py 4096 3 $P > $OUT/lt_$P.log 2>&1
   python3 $ROOT/tools/layer_table.py $(find $OUT/lt_$P -name '*kernel_trace.csv' | head -1) 4096 > $OUT/layer_table_$P.txt
   tail -1 $OUT/layer_table_$P.txt
 done
 # 3. HBM traffic: separate PMC passes (FETCH_SIZE uses 3 TCC slots, WRITE_SIZE 2)
-for P in fp32 bf16; do
+for P in fp32 bf16 fp32x3; do
   timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf_$P -o f --output-format csv -- python3 $ROOT/tools/profile_forward.py 2048 2 $P > $OUT/pf_$P.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pw_$P -o w --output-format csv -- python3 $ROOT/tools/profile_forward.py 2048 2 $P > $OUT/pw_$P.log 2>&1
   python3 $ROOT/tools/traffic_json.py $(find $OUT/pf_$P -name '*counter_collection.csv' | head -1) $(find $OUT/pw_$P -name '*counter_collection.csv' | head -1) 2048 2 > $OUT/traffic_$P.json
@@ -28,4 +28,5 @@ cat $OUT/stage_roofline.jsonl | cut -c1-170
 # 5. plain bench lines (no profiler attached)
 timeout -k 10 300 python3 $ROOT/bench.py > $OUT/bench_fp32.json 2> $OUT/bench_fp32.err
 timeout -k 10 300 python3 $ROOT/bench.py --precision bf16 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
-cut -c1-200 $OUT/bench_fp32.json; cut -c1-200 $OUT/bench_bf16.json
+timeout -k 10 300 python3 $ROOT/bench.py --precision fp32x3 > $OUT/bench_fp32x3.json 2> $OUT/bench_fp32x3.err
+cut -c1-200 $OUT/bench_fp32.json; cut -c1-200 $OUT/bench_bf16.json; cut -c1-200 $OUT/bench_fp32x3.json

@@ -4,20 +4,20 @@ set -e
 cd "$(dirname "$0")/.."
 R=${1:-r01}
 cp $(find gpurun_out/rp/bench -name '*kernel_stats.csv' | head -1) profiles/${R}_bench_kernel_stats.csv
-for P in fp32 bf16; do
+for P in fp32 bf16 fp32x3; do
   python3 tools/layer_table.py gpurun_out/rp/lt_$P/t_kernel_trace.csv 4096 > profiles/${R}_layer_table_$P.txt
   cp gpurun_out/rp/bench_$P.json profiles/${R}_bench_line_$P.json
 done
 cp gpurun_out/rp/stage_roofline.jsonl profiles/${R}_stage_roofline_host_timed.jsonl
 python3 - <<PY
 import json
-f=json.load(open('gpurun_out/rp/traffic_fp32.json')); b=json.load(open('gpurun_out/rp/traffic_bf16.json'))
+f=json.load(open('gpurun_out/rp/traffic_fp32.json')); b=json.load(open('gpurun_out/rp/traffic_bf16.json')); x=json.load(open('gpurun_out/rp/traffic_fp32x3.json'))
 p='profiles/${R}_backbone_traffic.json'
 old=json.load(open(p))
-old['fp32']=dict(f, algorithmic_bytes_per_crop=8396928); old['bf16']=dict(b, algorithmic_bytes_per_crop=4222080)
+old['fp32']=dict(f, algorithmic_bytes_per_crop=8396928); old['bf16']=dict(b, algorithmic_bytes_per_crop=4222080); old['fp32x3']=dict(x, algorithmic_bytes_per_crop=8396928)
 json.dump(old,open(p,'w'),indent=1)
-for q in ('fp32','bf16'):
+for q in ('fp32','bf16','fp32x3'):
     d=json.load(open('profiles/${R}_bench_line_%s.json'%q)); r=d['roofline']
     print(q, round(d['value']), round(d['ms_per_step'],2), 'TF', round(r['achieved'],1), round(r['frac'],4), 'hbm', round(r['hbm_view']['achieved']), round(r['hbm_view']['frac'],3), 'traffic', r['traffic'], 'pcie', round(d['pcie_inclusive']['value']), 'cpu', round(d['cpu_baseline']['value'],1), 'parity mm', d['parity_sample_max_mm'], 'rec', round(d['recurrent']['value_per_gpu']))
 PY
-tail -1 profiles/${R}_layer_table_fp32.txt; tail -1 profiles/${R}_layer_table_bf16.txt
+tail -1 profiles/${R}_layer_table_fp32.txt; tail -1 profiles/${R}_layer_table_bf16.txt; tail -1 profiles/${R}_layer_table_fp32x3.txt

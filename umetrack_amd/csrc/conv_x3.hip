@@ -10,6 +10,9 @@
 // v_mfma_f32_32x32x16_bf16, whose rate is 16x that of v_mfma_f32_32x32x2_f32: six of them per fp32
 // product leave 2.67x the fp32 pipe's arithmetic rate.  Results are NOT bit-identical to the fmaf-chain
 // kernel (conv_igemm.hip), they agree with it to fp32 rounding noise; tests/test_gpu_x3.py states the bound.
+// (The split is exact for |x| >= 2^-110; below that the low pieces underflow and the sum is off by < 2^-133.)
+// Finite operands are assumed: an infinite activation splits into (inf, NaN, NaN) and poisons its outputs
+// with NaN where the fp32 kernel would give inf; NaN propagates as NaN in both.
 //
 // Interface and structure are those of conv3x3s1_halo_f32: fp32 channels-last rows in and out, fp32
 // epilogue (conv bias -> BN -> residual -> ReLU), one flattened halo range of pixel rows staged per
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_x3(ConvS2ArgsX3 g) {
 
 bool conv_s2_x3_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w) {
   static const bool off = getenv("UMT_X3_NOS2") != nullptr;     // A/B switch for profiling
-  if (off || !c1.wx3 || (ds && !ds->wx3) || c1.cin_s % 16 != 0 || c1.cout_w % 64 != 0) return false;
+  if (off || !c1.wx3 || (ds && !ds->wx3) || c1.cin_s % 16 != 0 || c1.cout_w % 128 != 0) return false;   // see below for 64
   return conv_s2_fused_applicable(c1, ds, h, w);
 }
 
@@ -404,13 +407,13 @@ int launch_conv_s2_fused_x3(const ConvLayer& c1, const ConvLayer* ds, const floa
   size_t lds = (size_t)(g.rows_cap + 1) * X3_ROW;
   const size_t patch = (size_t)4 * 32 * LDA * sizeof(float);
   if (lds < patch) lds = patch;
-  const bool wide = c1.cout_w % 128 == 0;
-  dim3 grid((a.M + X3S2_BM - 1) / X3S2_BM, c1.cout_w / (wide ? 128 : 64));
-  void (*kern)(ConvS2ArgsX3) = wide ? (ds ? conv3x3s2_ds_x3<1, 2, true> : conv3x3s2_ds_x3<1, 2, false>)
-                                    : (ds ? conv3x3s2_ds_x3<2, 1, true> : conv3x3s2_ds_x3<2, 1, false>);
+  // 128-wide cout tiles only.  The <2, 1> arrangement (64-wide tiles) was measured on the 32->64 layer at 48x48: its
+  // 433 staged rows need 90 KB of LDS, one workgroup per CU, 1.17 ms against 1.09 ms for conv3x3s2_ds_f32.
+  dim3 grid((a.M + X3S2_BM - 1) / X3S2_BM, c1.cout_w / 128);
+  void (*kern)(ConvS2ArgsX3) = ds ? conv3x3s2_ds_x3<1, 2, true> : conv3x3s2_ds_x3<1, 2, false>;
   if (lds > 65536) {
-    static unsigned char done[4][64];
-    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done[(ds ? 1 : 0) + (wide ? 2 : 0)]));
+    static unsigned char done[2][64];
+    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done[ds ? 1 : 0]));
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   UMT_CHECK_HIP(hipGetLastError());
