@@ -155,7 +155,7 @@ if rank == 0:
     assert abs(fin.mpjpe - full["mpjpe"]) < 1e-9 and abs(fin.mpjpa - full["mpjpa"]) < 1e-9, (fin, full)
     assert fin.n_valid == full["n_valid"] and abs(fin.auc - full["auc"]) < 1e-9
     assert udist.max_over_ranks(float(rank)) == world - 1
-    print("OK", world)
+    sys.stdout.write(f"OK {world}\n")  # one write per rank: two ranks share the pipe
 else:
     udist.max_over_ranks(float(rank))
 udist.barrier()
@@ -190,7 +190,7 @@ def run_chunk(c):                                   # stands in for StreamRunner
 acc, (c0, c1) = run_sharded(n_chunks, rank, world, run_chunk, torch.zeros(2, dtype=torch.float64))
 assert seen == list(range(c0, c1)) and 0 <= c1 - c0 - n_chunks // world <= 1
 assert acc.tolist() == [n_chunks * (n_chunks - 1) / 2, 2.0 * 1_000_000], acc
-print("STREAM OK", world)
+sys.stdout.write(f"STREAM OK {world}\n")  # one write per rank: two ranks share the pipe
 udist.barrier()
 '''
 
