@@ -166,6 +166,18 @@ int umt_model_forward(umt_model* m, int head, int precision, const float* images
 int umt_model_timing_enable(umt_model* m, int on);
 int umt_model_timing_read(umt_model* m, double* backbone_ms, double* forward_ms, int* calls);
 
+/* ---- measurement aid, no counterpart in the reference: per-launch timing of the backbone.  When enabled,
+ * every backbone pass (umt_model_forward, umt_backbone_forward) records one HIP event on the caller's stream
+ * before the stem and one after each launch.  umt_model_layer_timing_read waits for the last event and sums,
+ * per position k in the (fixed) launch schedule, over all passes since the last enable: the elapsed time
+ * ms[k], the algorithmic FLOP flop[k] (true channel counts) and the number of launches launches[k];
+ * names is a caller buffer of max_layers x 48 bytes that receives "<kind> <cin>-><cout> hw<H> s<stride>".
+ * The events sit between the launches, so a pass measured this way is a little slower than an unmarked one;
+ * bench.py runs it outside its timed region.                                                              */
+int umt_model_layer_timing_enable(umt_model* m, int on);
+int umt_model_layer_timing_read(umt_model* m, int max_layers, char* names, double* flop, double* ms,
+                                int* launches, int* n_layers);
+
 /* ---- A14: skin_landmarks, lib/common/hand_skinning.py:189-209 (+ the right-hand mirror of
  * landmarks_from_hand_pose, lib/tracker/perspective_crop.py:40-51 when mirror_right != 0) ----
  * joint_angles dev f32 (b,22); wrist dev f32 (b,4,4); hand model arrays dev with n_model in {1,b}:

@@ -22,6 +22,12 @@ for P in fp32 bf16 fp32x3; do
   python3 $ROOT/tools/traffic_json.py $(find $OUT/pf_$P -name '*counter_collection.csv' | head -1) $(find $OUT/pw_$P -name '*counter_collection.csv' | head -1) 2048 2 > $OUT/traffic_$P.json
   cat $OUT/traffic_$P.json
 done
+# 3b. matrix-pipe busy fraction and clock per kernel (its own PMC pass: 2 SQ + 1 GRBM counters)
+for P in fp32 bf16 fp32x3; do
+  timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pm_$P -o m --output-format csv -- python3 $ROOT/tools/profile_forward.py 2048 2 $P > $OUT/pm_$P.log 2>&1
+  python3 $ROOT/tools/pmc_table.py $(find $OUT/pm_$P -name '*counter_collection.csv' | head -1) > $OUT/mfma_busy_$P.txt
+  head -4 $OUT/mfma_busy_$P.txt
+done
 # 4. the small stages, host-timed
 timeout -k 10 120 python3 $ROOT/tools/stage_roofline.py > $OUT/stage_roofline.jsonl 2>/dev/null
 cat $OUT/stage_roofline.jsonl | cut -c1-170

@@ -7,6 +7,7 @@ cp $(find gpurun_out/rp/bench -name '*kernel_stats.csv' | head -1) profiles/${R}
 for P in fp32 bf16 fp32x3; do
   python3 tools/layer_table.py gpurun_out/rp/lt_$P/t_kernel_trace.csv 4096 > profiles/${R}_layer_table_$P.txt
   cp gpurun_out/rp/bench_$P.json profiles/${R}_bench_line_$P.json
+  [ -s gpurun_out/rp/mfma_busy_$P.txt ] && cp gpurun_out/rp/mfma_busy_$P.txt profiles/${R}_mfma_busy_$P.txt
 done
 cp gpurun_out/rp/stage_roofline.jsonl profiles/${R}_stage_roofline_host_timed.jsonl
 python3 - <<PY

@@ -50,6 +50,8 @@ SIGNATURES = {
                                   _P, _P, _P, _P, _P, c_int64, _P]),
     "umt_model_timing_enable": (c_int, [_P, c_int]),
     "umt_model_timing_read": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
+    "umt_model_layer_timing_enable": (c_int, [_P, c_int]),
+    "umt_model_layer_timing_read": (c_int, [_P, c_int, _P, POINTER(c_double), POINTER(c_double), POINTER(c_int), POINTER(c_int)]),
     "umt_fk_landmarks": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_float, c_int, _P, _P]),
     "umt_metric_workspace_bytes": (c_int64, [c_int, c_int]),
     "umt_metric_partials": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, _P]),

@@ -77,6 +77,12 @@ struct umt_model {
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;   // 3 per recorded call
   size_t ev_used = 0;
+  // optional per-launch timing of the backbone (umt_model_layer_timing_*): one event before the stem and one
+  // after every launch; a mark names the launch that ended at the event of the same index
+  struct LayerMark { char name[48]; double flop; };
+  bool layer_timing = false;
+  std::vector<hipEvent_t> lev_pool;
+  std::vector<LayerMark> lev_marks;
 };
 
 namespace umt {
@@ -346,6 +352,34 @@ static int check_ready(const umt_model* m) {
   return 0;
 }
 
+// ---- per-launch timing of the backbone (measurement aid) ----
+// name == nullptr: the mark that opens a backbone pass.  flop: algorithmic, true channel counts.
+static int layer_mark(umt_model* m, hipStream_t s, const char* name, double flop) {
+  if (!m->layer_timing) return 0;
+  const size_t k = m->lev_marks.size();
+  if (m->lev_pool.size() <= k) {
+    hipEvent_t e;
+    UMT_CHECK_HIP(hipEventCreate(&e));
+    m->lev_pool.push_back(e);
+  }
+  umt_model::LayerMark mk;
+  snprintf(mk.name, sizeof(mk.name), "%s", name ? name : "");
+  mk.flop = name ? flop : -1.0;
+  m->lev_marks.push_back(mk);
+  UMT_CHECK_HIP(hipEventRecord(m->lev_pool[k], s));
+  return 0;
+}
+
+static int conv_mark(umt_model* m, hipStream_t s, const char* kind, const ConvLayer& L, const ConvLayer* ds, int n, int hw) {
+  if (!m->layer_timing) return 0;
+  const int ho = hw / L.stride;
+  double flop = 2.0 * L.taps * L.cin * L.cout * (double)n * ho * ho;
+  if (ds) flop += 2.0 * ds->taps * ds->cin * ds->cout * (double)n * ho * ho;
+  char name[48];
+  snprintf(name, sizeof(name), "%s %d->%d hw%d s%d", kind, L.cin, L.cout, hw, L.stride);
+  return layer_mark(m, s, name, flop);
+}
+
 // ---- stages on channels-last rows ----
 // Blocks [b0, b1) on n crops whose rows start at x; returns the buffer that holds the result.
 // x/t/y rotate; the down-sample branch goes to d.
@@ -363,19 +397,24 @@ static int run_blocks(umt_model* m, bool x3, size_t b0, size_t b1, int n, float*
     const float* res = x;
     if (B.has_down && x3 && conv_s2_x3_applicable(B.conv1, &B.down, hw, hw)) {
       UMT_TRY(launch_conv_s2_fused_x3(B.conv1, &B.down, x, n, hw, hw, t, d, s));
+      UMT_TRY(conv_mark(m, s, "c1+ds", B.conv1, &B.down, n, hw));
       res = d;
     } else if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
       UMT_TRY(launch_conv_s2_fused(B.conv1, &B.down, x, n, hw, hw, t, d, s));     // conv1 and the down-sample branch
+      UMT_TRY(conv_mark(m, s, "c1+ds", B.conv1, &B.down, n, hw));
       res = d;
     } else {
       UMT_TRY(conv_f32(B.conv1, x3, x, n, hw, nullptr, t, s));
+      UMT_TRY(conv_mark(m, s, "c1", B.conv1, nullptr, n, hw));
       if (B.has_down) {
         UMT_TRY(launch_conv(B.down, x, n, hw, hw, nullptr, d, s));
+        UMT_TRY(conv_mark(m, s, "ds", B.down, nullptr, n, hw));
         res = d;
       }
     }
     const int hw2 = hw / B.conv1.stride;
     UMT_TRY(conv_f32(B.conv2, x3, t, n, hw2, res, y, s));
+    UMT_TRY(conv_mark(m, s, res ? "c2+res" : "c2", B.conv2, nullptr, n, hw2));
     float* old = x;
     x = y;
     y = old;
@@ -392,6 +431,7 @@ static int backbone_rows(umt_model* m, bool x3, const float* images, int n, cons
   float *x = w.a, *t = w.b, *y = w.c;
   const int sub = stage1_sub();
   size_t first = 0;
+  UMT_TRY(layer_mark(m, s, nullptr, 0));
   if (sub > 0 && sub < n) {
     // Stage 1 (stem + 2 blocks at 48x48x32, 295 KB per crop per tensor) depth-first over groups of
     // `sub` crops, so that a group's three live tensors stay in the 256 MB Infinity Cache between
@@ -403,6 +443,7 @@ static int backbone_rows(umt_model* m, bool x3, const float* images, int n, cons
       const size_t off = (size_t)c0 * ACT_FLOATS;
       float *xs = w.a + off, *ts = w.b + off, *ys = w.c + off;
       UMT_TRY(launch_stem(m->stem, images + (size_t)c0 * 96 * 96, nc, xs, s));
+      UMT_TRY(layer_mark(m, s, "stem 1->32 hw96", 2.0 * 9 * 32 * 96.0 * 96.0 * nc));
       UMT_TRY(run_blocks(m, x3, 0, nb1, nc, xs, ts, ys, w.d, s));
       xe = xs - off; te = ts - off; ye = ys - off;    // same rotation for every group
     }
@@ -410,9 +451,11 @@ static int backbone_rows(umt_model* m, bool x3, const float* images, int n, cons
     first = nb1;
   } else {
     UMT_TRY(launch_stem(m->stem, images, n, x, s));
+    UMT_TRY(layer_mark(m, s, "stem 1->32 hw96", 2.0 * 9 * 32 * 96.0 * 96.0 * n));
   }
   UMT_TRY(run_blocks(m, x3, first, m->blocks.size(), n, x, t, y, w.d, s));
   UMT_TRY(launch_conv(m->proj, x, n, 6, 6, nullptr, w.feat, s));
+  UMT_TRY(conv_mark(m, s, "proj", m->proj, nullptr, n, 6));
   return 0;
 }
 
@@ -426,16 +469,20 @@ static int run_blocks_bf16(umt_model* m, size_t b0, size_t b1, int n, uint16_t*&
     const uint16_t* res = x;
     if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
       UMT_TRY(launch_conv_s2_fused_bf16(B.conv1, &B.down, x, n, hw, hw, t, d, s));
+      UMT_TRY(conv_mark(m, s, "c1+ds", B.conv1, &B.down, n, hw));
       res = d;
     } else {
       UMT_TRY(launch_conv_bf16(B.conv1, x, n, hw, hw, nullptr, t, 0, s));
+      UMT_TRY(conv_mark(m, s, "c1", B.conv1, nullptr, n, hw));
       if (B.has_down) {
         UMT_TRY(launch_conv_bf16(B.down, x, n, hw, hw, nullptr, d, 0, s));
+        UMT_TRY(conv_mark(m, s, "ds", B.down, nullptr, n, hw));
         res = d;
       }
     }
     const int hw2 = hw / B.conv1.stride;
     UMT_TRY(launch_conv_bf16(B.conv2, t, n, hw2, hw2, res, y, 0, s));
+    UMT_TRY(conv_mark(m, s, "c2+res", B.conv2, nullptr, n, hw2));
     uint16_t* old = x;
     x = y;
     y = old;
@@ -447,6 +494,7 @@ static int backbone_rows_bf16(umt_model* m, const float* images, int n, const Ba
   uint16_t *x = (uint16_t*)w.a, *t = (uint16_t*)w.b, *y = (uint16_t*)w.c, *d = (uint16_t*)w.d;
   const int sub = stage1_sub();
   size_t first = 0;
+  UMT_TRY(layer_mark(m, s, nullptr, 0));
   if (sub > 0 && sub < n) {
     const size_t nb1 = (size_t)N_STAGE_BLOCKS[0];
     uint16_t *xe = x, *te = t, *ye = y;
@@ -455,6 +503,7 @@ static int backbone_rows_bf16(umt_model* m, const float* images, int n, const Ba
       const size_t off = (size_t)c0 * ACT_FLOATS;
       uint16_t *xs = x + off, *ts = t + off, *ys = y + off;
       UMT_TRY(launch_stem_bf16(m->stem, images + (size_t)c0 * 96 * 96, nc, xs, s));
+      UMT_TRY(layer_mark(m, s, "stem 1->32 hw96", 2.0 * 9 * 32 * 96.0 * 96.0 * nc));
       UMT_TRY(run_blocks_bf16(m, 0, nb1, nc, xs, ts, ys, d, s));
       xe = xs - off; te = ts - off; ye = ys - off;
     }
@@ -462,9 +511,11 @@ static int backbone_rows_bf16(umt_model* m, const float* images, int n, const Ba
     first = nb1;
   } else {
     UMT_TRY(launch_stem_bf16(m->stem, images, n, x, s));
+    UMT_TRY(layer_mark(m, s, "stem 1->32 hw96", 2.0 * 9 * 32 * 96.0 * 96.0 * n));
   }
   UMT_TRY(run_blocks_bf16(m, first, m->blocks.size(), n, x, t, y, d, s));
   UMT_TRY(launch_conv_bf16(m->proj, x, n, 6, 6, nullptr, w.feat, 1, s));
+  UMT_TRY(conv_mark(m, s, "proj", m->proj, nullptr, n, 6));
   return 0;
 }
 
@@ -546,6 +597,7 @@ extern "C" int umt_model_destroy(umt_model* m) {
       if (m->mem) (void)hipFree(m->mem);
       if (m->prev_ext) (void)hipFree(m->prev_ext);
       for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
+      for (hipEvent_t e : m->lev_pool) (void)hipEventDestroy(e);
       (void)hipSetDevice(prev);
     }
   }
@@ -948,5 +1000,39 @@ extern "C" int umt_model_timing_read(umt_model* m, double* backbone_ms, double* 
   *backbone_ms = b;
   *forward_ms = f;
   *calls = (int)(m->ev_used / 3);
+  return 0;
+}
+
+extern "C" int umt_model_layer_timing_enable(umt_model* m, int on) {
+  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
+  m->layer_timing = on != 0;
+  m->lev_marks.clear();
+  return 0;
+}
+
+extern "C" int umt_model_layer_timing_read(umt_model* m, int max_layers, char* names, double* flop, double* ms,
+                                           int* launches, int* n_layers) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(max_layers > 0 && names && flop && ms && launches && n_layers, UMT_ERR_INVALID, "layer_timing_read: bad argument");
+  // launch k of a backbone pass is aggregated with launch k of every other pass (the schedule is fixed per precision)
+  int pos = 0, count = 0;
+  for (int i = 0; i < max_layers; ++i) { flop[i] = 0; ms[i] = 0; launches[i] = 0; names[(size_t)i * 48] = 0; }
+  if (!m->lev_marks.empty()) UMT_CHECK_HIP(hipEventSynchronize(m->lev_pool[m->lev_marks.size() - 1]));
+  for (size_t k = 0; k < m->lev_marks.size(); ++k) {
+    const umt_model::LayerMark& mk = m->lev_marks[k];
+    if (mk.flop < 0) { pos = 0; continue; }       // opening mark of a pass
+    UMT_REQUIRE(k > 0, UMT_ERR_STATE, "layer_timing_read: launch mark without an opening mark");
+    if (pos < max_layers) {
+      float t = 0;
+      UMT_CHECK_HIP(hipEventElapsedTime(&t, m->lev_pool[k - 1], m->lev_pool[k]));
+      if (launches[pos] == 0) memcpy(names + (size_t)pos * 48, mk.name, 48);
+      flop[pos] += mk.flop;
+      ms[pos] += t;
+      launches[pos] += 1;
+      if (pos + 1 > count) count = pos + 1;
+    }
+    ++pos;
+  }
+  *n_layers = count;
   return 0;
 }

@@ -155,6 +155,20 @@ class UmeTrackModel:
             nat.check(nat.lib().umt_model_timing_read(self._h, ctypes.byref(b), ctypes.byref(f), ctypes.byref(c)))
         return b.value, f.value, c.value
 
+    def layer_timing_enable(self, on: bool = True) -> None:
+        nat.check(nat.lib().umt_model_layer_timing_enable(self._h, int(on)))
+
+    def layer_timing_read(self, max_layers: int = 64):
+        """Per backbone launch, in schedule order: (name, flop, ms, launches), summed over the passes since
+        layer_timing_enable(True); HIP events recorded by the library between the launches."""
+        names = ctypes.create_string_buffer(48 * max_layers)
+        flop, ms = (ctypes.c_double * max_layers)(), (ctypes.c_double * max_layers)()
+        cnt, n = (ctypes.c_int * max_layers)(), ctypes.c_int()
+        with torch.cuda.device(self._device):
+            nat.check(nat.lib().umt_model_layer_timing_read(self._h, max_layers, names, flop, ms, cnt, ctypes.byref(n)))
+        raw = names.raw
+        return [(raw[48 * i:48 * (i + 1)].split(b"\0", 1)[0].decode(), flop[i], ms[i], cnt[i]) for i in range(n.value)]
+
     # ---- forward ----
     def _forward(self, head: int, fd: InputFrameData, desc: InputFrameDesc, skel: Optional[InputSkeletonData],
                  required_rows: Optional[int] = None) -> RegressorOutput:
