@@ -319,6 +319,13 @@ def main():
               "note": "UMT_PREC_FP32_BF16X3: fp32 tensors; each fp32 operand of the stride-1 3x3 backbone layers is the exact "
                       "sum of three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulation; 2 timed steps"}
 
+    # per-launch view of the backbone (outside the timed region: the library records a HIP event between every two
+    # launches, which costs a little): one more step in the headline precision
+    pipe.model.layer_timing_enable(True)
+    pipe.step()
+    layer_rows = pipe.model.layer_timing_read()
+    pipe.model.layer_timing_enable(False)
+
     # second mode of section 8(d): the same batch as 64-frame recordings in lock-step with the temporal
     # memory ON (bulk backbone, then T sequential memory+regressor steps); per-rank, no collective
     from umetrack_amd import bulk
@@ -362,6 +369,14 @@ def main():
                            f"fp32 multiply-add once (= {achieved / FP32_MATRIX_PEAK_TFLOPS:.3f} of the fp32 matrix peak)"}[args.precision]
     act_bytes = backbone_activation_bytes_per_crop(2 if bf16 else 4) * crops_per_call
     hbm_achieved = act_bytes / (bb_ms / calls * 1e-3) / 1e9
+    # the dominant kernel: the stride-1 3x3 layers with 128 and 256 channels all run one template instance (with and
+    # without residual); its launches are rows of the rocprofv3 --kernel-trace --stats summary under profiles/
+    dom = [r for r in layer_rows if r[0].split()[0] in ("c1", "c2+res") and int(r[0].split()[1].split("->")[1]) >= 128]
+    dom_kernel = {"fp32": "conv3x3s1_halo_f32<2,2,2,2,RES>", "bf16": "conv3x3s1_halo_bf16<2,2,2,2,RES>",
+                  "fp32x3": "conv3x3s1_halo_x3<2,2,2,2,RES>"}[args.precision]
+    dom_launches = sum(r[3] for r in dom)
+    dom_ms = sum(r[2] for r in dom) / max(dom_launches, 1)
+    dom_flop = sum(r[1] for r in dom) / max(dom_launches, 1)
     line = {
         "metric": "hand-frames/sec (4-view)", "value": hands_per_step * args.steps / elapsed, "unit": "hand-frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -385,7 +400,15 @@ def main():
                                                           "fp32x3": "conv3x3s1_halo_x3 / conv3x3s2_ds_x3 (+ conv3x3s2_ds_f32, conv_igemm_f32)"}[args.precision]
                                + " launches per forward call",
                      "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
-                     "forward_avg_ms": fwd_ms / calls, "calls": calls},
+                     "forward_avg_ms": fwd_ms / calls, "calls": calls,
+                     "dominant_kernel": {"kernel": dom_kernel, "launches_per_call": dom_launches,
+                                         "share_of_backbone_time": sum(r[2] for r in dom) / max(sum(r[2] for r in layer_rows), 1e-9),
+                                         "flop_per_launch": dom_flop, "avg_ms": dom_ms,
+                                         "achieved": dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else None,
+                                         "frac": dom_flop / (dom_ms * 1e-3) / 1e12 / peak if dom_ms > 0 else None,
+                                         "note": "HIP events recorded by the library between the launches of one extra step after "
+                                                 "the timed region; stride-1 3x3 layers with 128 and 256 channels"},
+                     "layers": [{"launch": r[0], "ms": r[2] / max(r[3], 1), "tflops": r[1] / max(r[2], 1e-9) / 1e9} for r in layer_rows]},
         "model_tflops": MODEL_FLOP_PER_HAND * pipe.S * args.steps / elapsed / 1e12,
         "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa,
         "recurrent": {"value_per_gpu": pipe.S / rec_dt, "unit": "hand-frames/s", "ms_per_step": rec_dt * 1e3,

@@ -350,7 +350,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_halo_bf16(ConvArgsH a) {
     for (int tap = 0; tap < 9; ++tap) {
       if (tap < 7) load_b(bring[(tap + 2) % 3], tap + 2, chunk);
       else if (chunk + 1 < nchunks) load_b(bring[(tap + 2) % 3], tap - 7, chunk + 1);
+#ifndef UMT_X_NOAPF      // experiment switch (tools/conv_bench.hip): wrong results, shows what the prefetch costs
       if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
