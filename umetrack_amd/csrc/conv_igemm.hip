@@ -161,8 +161,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvArgs a) {
 // the activations than the gather kernel above.  Weights do not go through LDS at all: each wave
 // streams its B fragments (already packed in fragment order) from L2 into registers, one tap
 // ahead of the MFMAs that consume them.
+#ifndef UMT_F32_MINB_1TILE
+#define UMT_F32_MINB_1TILE 2
+#endif
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
-__global__ __launch_bounds__(256, 2) void conv3x3s1_halo_f32(ConvArgs a) {
+__global__ __launch_bounds__(256, (TM * TN == 1 ? UMT_F32_MINB_1TILE : 2)) void conv3x3s1_halo_f32(ConvArgs a) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");

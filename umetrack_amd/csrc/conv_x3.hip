@@ -58,8 +58,11 @@ __device__ __forceinline__ void x3_split4(float4 v, uint2& p0, uint2& p1, uint2&
   p2.x = x3_split2(v.x, v.y); p2.y = x3_split2(v.z, v.w);
 }
 
+#ifndef UMT_X3_MINB_SMALL
+#define UMT_X3_MINB_SMALL 3
+#endif
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool RES>
-__global__ __launch_bounds__(256, 2) void conv3x3s1_halo_x3(ConvArgs a) {
+__global__ __launch_bounds__(256, (WAVES_N == 2 && TM * TN <= 2 ? UMT_X3_MINB_SMALL : 2)) void conv3x3s1_halo_x3(ConvArgs a) {
   constexpr int BM = WAVES_M * TM * 32;
   constexpr int BN = WAVES_N * TN * 32;
   static_assert(WAVES_M * WAVES_N == 4, "256-thread workgroup");
