@@ -300,9 +300,14 @@ __global__ __launch_bounds__(256, (TM * TN <= 2 ? UMT_HALO_MINB_SMALL : 1)) void
   const char* wblock = reinterpret_cast<const char*>(a.w + (size_t)n0 * 8);
   const size_t w_c16 = (size_t)2 * a.cout_w * 16;       // bytes per 16-channel group
   const size_t w_tap = (size_t)c16_total * w_c16;
-  // ring of three tap slots (9 taps per chunk, so the slot of a tap is static): the fragments of tap t+2
-  // are requested while tap t runs - two taps are only 8-16 MFMAs, about one L2 round trip
-  uint4 bring[3][2][TN];
+  // Weight fragments run ahead of their MFMAs through a register ring of three slots.  Two-tile waves (64-channel
+  // layers): a slot is a TAP (9 per chunk, so a tap's slot is static), the fragments of tap t+2 are requested while
+  // tap t runs.  Four-tile waves (128/256-channel layers): a slot is a K-STEP (one 16-channel group of one tap, 18
+  // per chunk), requested two k-steps = 8 MFMAs ahead: half the ring registers, 164 instead of 184 in all, which
+  // is a third wave per SIMD (-7 % on those layers; the two-tile kernel measured no gain from it).
+  constexpr bool KRING = TM * TN >= 4;
+  uint4 bring[KRING ? 1 : 3][2][TN];
+  uint4 bk[3][TN];
   // buffer loads: resource (base of the packed weights) and the (tap, channel group) offset are scalar, the
   // lane offset is one 32-bit VGPR computed once - no per-load 64-bit VALU address arithmetic
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -320,8 +325,22 @@ __global__ __launch_bounds__(256, (TM * TN <= 2 ? UMT_HALO_MINB_SMALL : 1)) void
       }
     }
   };
-  load_b(bring[0], 0, 0);
-  load_b(bring[1], 1, 0);
+  auto load_bk = [&](uint4 (&dst)[TN], int tap, int c16raw) {
+    const int c16 = min(c16raw, c16_total - 1);
+    const int soff = (int)(tap * w_tap + c16 * w_c16);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + j * 512, soff, 0);
+      dst[j] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+  if constexpr (KRING) {
+    load_bk(bk[0], 0, 0);
+    load_bk(bk[1], 0, 1);
+  } else {
+    load_b(bring[0], 0, 0);
+    load_b(bring[1], 1, 0);
+  }
 
   constexpr int NLD = ((BM + 2 * 48 + 2) * 4 + 255) / 256;
   uint4 areg[NLD];
@@ -351,13 +370,30 @@ __global__ __launch_bounds__(256, (TM * TN <= 2 ? UMT_HALO_MINB_SMALL : 1)) void
       if ((idx >> 2) < rows) *reinterpret_cast<uint4*>(sAh + ((idx >> 2) * LDH + 8 * (idx & 3)) * 2) = v;
     }
     __syncthreads();
+    if constexpr (KRING) {
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks) {
+      const int nk = ks + 2;
+      if (nk < 18) load_bk(bk[nk % 3], nk >> 1, chunk * 2 + (nk & 1));
+      else if (chunk + 1 < nchunks) load_bk(bk[nk % 3], (nk - 18) >> 1, (chunk + 1) * 2 + (nk & 1));
+      if (ks == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 av[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        av[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sAh + arow[i][ks >> 1] + (ks & 1) * 32));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bk[ks % 3][j]), acc[i][j], 0, 0, 0);
+    }
+    } else {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (tap < 7) load_b(bring[(tap + 2) % 3], tap + 2, chunk);
-      else if (chunk + 1 < nchunks) load_b(bring[(tap + 2) % 3], tap - 7, chunk + 1);
-#ifndef UMT_X_NOAPF      // experiment switch (tools/conv_bench.hip): wrong results, shows what the prefetch costs
+      if (tap < 7) load_b(bring[(tap + 2) % (KRING ? 1 : 3)], tap + 2, chunk);
+      else if (chunk + 1 < nchunks) load_b(bring[(tap + 2) % (KRING ? 1 : 3)], tap - 7, chunk + 1);
       if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
@@ -369,8 +405,9 @@ __global__ __launch_bounds__(256, (TM * TN <= 2 ? UMT_HALO_MINB_SMALL : 1)) void
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bring[tap % 3][c][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], __builtin_bit_cast(bf16x8, bring[tap % (KRING ? 1 : 3)][c][j]), acc[i][j], 0, 0, 0);
       }
+    }
     }
     __syncthreads();
   }
