@@ -249,6 +249,180 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ 64 -> 64, weights in LDS
+// Same persistent ping-pong scheme for the 64 -> 64 channel stride-1 3x3 layers of stage 2 (W <= 24).  Their
+// packed weights (73.7 KB of bf16) do not fit in registers but do fit in LDS beside two halo ranges, so the
+// workgroup copies them in once and the tap loop reads BOTH operands from LDS: no global load sits between two
+// MFMAs, and the next tile's halo range and this tile's residual rows are in flight during the whole MFMA
+// phase.  One workgroup per CU (162.9 KB of LDS), 128-pixel tiles, a wave owns 32 pixels x 64 channels.
+// k order (32-channel chunk, tap, 16-channel group) is conv3x3s1_halo_bf16's: results are bit-identical to it.
+constexpr int W64_LDA = 72;                    // bf16 per LDS row: 64 channels + 16 B (144 B; 16 rows -> 16 distinct slots)
+constexpr int W64_BM = 128;
+constexpr int W64_WMAX = 24;
+constexpr int W64_WBYTES = 9 * 64 * 64 * 2;    // packed weights [9][4][2][64][8] bf16
+constexpr int W64_CBYTES = 3 * 64 * 4;         // bias, scale, shift
+
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
+  constexpr int BM = W64_BM;
+  constexpr int NLD = ((BM + 2 * W64_WMAX + 2) * 8 + 255) / 256;   // uint4 slots per thread for one halo range
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, group = threadIdx.x >> 8;
+  const int a_bytes = ((rows + 1) * W64_LDA * 2 + 15) & ~15;      // halo range + the all-zero row
+  unsigned char* sW = smem_w;
+  const float* sC = reinterpret_cast<const float*>(smem_w + W64_WBYTES);
+  unsigned char* sA = smem_w + W64_WBYTES + W64_CBYTES + group * (a_bytes + 4 * 32 * T_LDP * 4);
+  float* patch = reinterpret_cast<float*>(sA + a_bytes) + wave * 32 * T_LDP;
+  const int li = lane & 31, lh = lane >> 5;
+  const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+  const uint16_t* resid = reinterpret_cast<const uint16_t*>(a.residual);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out);
+
+  // weights and the epilogue constants -> LDS, once per workgroup
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+    for (int i = threadIdx.x; i < W64_WBYTES / 16; i += 512) *reinterpret_cast<uint4*>(sW + 16 * i) = wp[i];
+    float* c = reinterpret_cast<float*>(smem_w + W64_WBYTES);
+    if (threadIdx.x < 64) {
+      c[threadIdx.x] = a.bias[threadIdx.x];
+      c[64 + threadIdx.x] = a.scale[threadIdx.x];
+      c[128 + threadIdx.x] = a.shift[threadIdx.x];
+    }
+  }
+  const int q = lane & 3, rsub = lane >> 2;
+
+  const GroupWalk gw = group_walk(a.ntiles, group);
+  const GroupWalk g0 = group_walk(a.ntiles, 0);
+  const int nphase = 2 * g0.count + 1;
+
+  uint4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int tile) {
+    const int gbase = tile * BM - W - 1;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 3, qq = idx & 7;
+      const int g = gbase + r;
+      const bool ok = r < rows && g >= 0 && g < a.M;
+      const size_t off = ok ? (size_t)g * 64 + 8 * qq : 0;
+      areg[k] = *reinterpret_cast<const uint4*>(in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto write_a = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      uint4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+      if ((idx >> 3) < rows) *reinterpret_cast<uint4*>(sA + ((idx >> 3) * W64_LDA + 8 * (idx & 7)) * 2) = v;
+    }
+  };
+
+  if (tid < W64_LDA * 2 / 16) *reinterpret_cast<uint4*>(sA + rows * W64_LDA * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
+  if (gw.count > 0) {
+    load_a(gw.first);
+    write_a();
+  }
+  __syncthreads();
+
+  f32x16 acc[2];
+  uint4 res[2][2];
+  for (int ph = 0; ph < nphase; ++ph) {
+    const int j = (ph - group) >> 1;
+    const bool mfma_phase = ((ph - group) & 1) == 0;
+    if (ph >= group && j < gw.count) {
+      const int t = gw.first + j * gw.step;
+      const int mw = t * BM + wave * 32;
+      if (mfma_phase) {
+        if (j + 1 < gw.count) load_a(t + gw.step);
+        if (RES) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int m = mw + 16 * k + rsub;
+              const size_t off = m < a.M ? (size_t)m * 64 + n * 32 + 8 * q : 0;
+              res[n][k] = *reinterpret_cast<const uint4*>(resid + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int arow[9];      // byte offset of the lane's operand row per tap; the zero row where padded
+        {
+          const unsigned mk = border_mask(mw + li, a.M, H, W, a.mg_hw, a.mg_w);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+            arow[tap] = ((((mk >> tap) & 1u) ? wave * 32 + li + (tap / 3) * W + (tap % 3) : rows) * W64_LDA + 8 * lh) * 2;
+        }
+        const unsigned char* bl = sW + (lh * 64 + li) * 16;       // + ((tap * 4 + c16) * 2) * 64 * 16 + n * 512
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+        for (int chunk = 0; chunk < 2; ++chunk)
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int c16 = chunk * 2 + c;
+              const uint4 av = *reinterpret_cast<const uint4*>(sA + arow[tap] + c16 * 32);
+#pragma unroll
+              for (int n = 0; n < 2; ++n) {
+                const uint4 bv = *reinterpret_cast<const uint4*>(bl + (tap * 4 + c16) * 2048 + n * 512);
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
+                                                                 acc[n], 0, 0, 0);
+              }
+            }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int co = n * 32 + 8 * q;
+          const float4 cb0 = *reinterpret_cast<const float4*>(sC + co), cb1 = *reinterpret_cast<const float4*>(sC + co + 4);
+          const float4 cs0 = *reinterpret_cast<const float4*>(sC + 64 + co), cs1 = *reinterpret_cast<const float4*>(sC + 64 + co + 4);
+          const float4 ch0 = *reinterpret_cast<const float4*>(sC + 128 + co), ch1 = *reinterpret_cast<const float4*>(sC + 128 + co + 4);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[n][r];
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int row = 16 * k + rsub;
+            const int m = mw + row;
+            float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+            float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+            v.x = (v.x + cb0.x) * cs0.x + ch0.x; v.y = (v.y + cb0.y) * cs0.y + ch0.y;
+            v.z = (v.z + cb0.z) * cs0.z + ch0.z; v.w = (v.w + cb0.w) * cs0.w + ch0.w;
+            u.x = (u.x + cb1.x) * cs1.x + ch1.x; u.y = (u.y + cb1.y) * cs1.y + ch1.y;
+            u.z = (u.z + cb1.z) * cs1.z + ch1.z; u.w = (u.w + cb1.w) * cs1.w + ch1.w;
+            if (RES) {
+              const uint4 rr = res[n][k];
+              v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+              v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+              u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
+              u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
+            }
+            if (a.relu) {
+              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+              u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+            }
+            if (m < a.M)
+              *reinterpret_cast<uint4*>(out + (size_t)m * 64 + co) =
+                  make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y),
+                             thin_pack_bf16x2(u.z, u.w));
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (j + 1 < gw.count) write_a();
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------- launch
 static int cu_count() {
   static int cached[64] = {0};
@@ -264,9 +438,14 @@ static int cu_count() {
 
 int g_conv_thin = -1;      // -1: decide from the environment once; 0 / 1: forced (tools/conv_bench.hip)
 
+static bool thin64_shape(const ConvLayer& L, int w) {
+  return L.taps == 9 && L.stride == 1 && L.cin_s == 64 && L.cout_s == 64 && L.cout_w == 64 && w <= W64_WMAX;
+}
+
 bool conv_thin_applicable(const ConvLayer& L, int w) {
   if (g_conv_thin < 0) g_conv_thin = getenv("UMT_CONV_NOTHIN") ? 0 : 1;     // A/B switch for profiling
-  return g_conv_thin && L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48;
+  if (!g_conv_thin || L.taps != 9 || L.stride != 1) return false;
+  return (L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48) || thin64_shape(L, w);
 }
 
 static int grid_for(int ntiles, int per_cu) {
@@ -284,7 +463,18 @@ static unsigned char g_thin_lds_done[2][64];
 static size_t thin_lds_bytes(int tm, int w) {
   return 2 * ((((size_t)(128 * tm + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
+static unsigned char g_w64_lds_done[2][64];
+static size_t w64_lds_bytes(int w) {
+  return (size_t)W64_WBYTES + W64_CBYTES +
+         2 * ((((size_t)(W64_BM + 2 * w + 2 + 1) * W64_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
+}
+static_assert((size_t)W64_WBYTES + W64_CBYTES + 2 * ((((size_t)(W64_BM + 2 * W64_WMAX + 2 + 1) * W64_LDA * 2 + 15) & ~(size_t)15) +
+                                                       4 * 32 * T_LDP * sizeof(float)) <= 160 * 1024,
+              "conv3x3_wlds64_bf16: LDS budget");
+
 int conv_thin_prepare_device() {      // largest request: W = 48
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[0]));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<true>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[1]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, false>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[0]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, true>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[1]));
   return 0;
@@ -299,6 +489,16 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
   ThinArgs a;
   a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift; a.residual = residual; a.out = out;
   a.H = h; a.W = w; a.M = (int)M; a.relu = L.relu;
+  if (thin64_shape(L, w)) {
+    a.ntiles = (int)((M + W64_BM - 1) / W64_BM);
+    a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+    a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
+    auto kern64 = residual ? conv3x3_wlds64_bf16<true> : conv3x3_wlds64_bf16<false>;
+    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern64), w64_lds_bytes(W64_WMAX), residual ? g_w64_lds_done[1] : g_w64_lds_done[0]));
+    hipLaunchKernelGGL(kern64, dim3(grid_for(a.ntiles, 1)), dim3(512), w64_lds_bytes(w), stream, a);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   a.ntiles = (int)((M + 128 * TM - 1) / (128 * TM));
   a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
