@@ -423,6 +423,204 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ 128 -> 128, weights streamed
+// The 128 -> 128 channel stride-1 3x3 layers of stage 3 (W <= 12) in the same persistent two-group scheme.  Their
+// weights (295 KB) fit neither registers nor LDS and stay where conv3x3s1_halo_bf16 has them: streamed from L2
+// through a register ring of K-STEP slots (one 16-channel group of one tap; 72 per tile), here six slots deep
+// because the workgroup is alone on its CU and has the registers.  What changes is everything around the
+// MFMAs: the whole 128-channel halo range of a tile sits in LDS (272-byte rows), so a tile's 288 MFMAs per wave
+// run without a barrier; the other group's epilogue, its residual rows and its next halo range overlap them;
+// and the activation / residual loads of a group are issued AFTER the last weight load of its MFMA phase, so
+// that no weight fragment queues behind an HBM access in the in-order load counter.  k order (32-channel chunk,
+// tap, 16-channel group) is conv3x3s1_halo_bf16's: bit-identical results.
+constexpr int S128_LDA = 136;                  // bf16 per LDS row: 128 channels + 16 B (272 B = 17 slots)
+constexpr int S128_BM = 128;
+constexpr int S128_WMAX = 12;
+constexpr int S128_CBYTES = 3 * 128 * 4;
+constexpr int S128_RING = 6;
+
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
+  constexpr int BM = S128_BM;
+  constexpr int NLD = ((BM + 2 * S128_WMAX + 2) * 16 + 255) / 256;   // uint4 slots per thread for one halo range
+  constexpr int R = S128_RING, NK = 72;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_s[];
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, group = threadIdx.x >> 8;
+  const int wm = wave >> 1, wn = wave & 1;                          // a wave owns 64 pixels x 64 channels
+  const int a_bytes = ((rows + 1) * S128_LDA * 2 + 15) & ~15;      // halo range + the all-zero row
+  const float* sC = reinterpret_cast<const float*>(smem_s);
+  unsigned char* sA = smem_s + S128_CBYTES + group * (a_bytes + 4 * 32 * T_LDP * 4);
+  float* patch = reinterpret_cast<float*>(sA + a_bytes) + wave * 32 * T_LDP;
+  const int li = lane & 31, lh = lane >> 5;
+  const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+  const uint16_t* resid = reinterpret_cast<const uint16_t*>(a.residual);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out);
+
+  if (threadIdx.x < 128) {
+    float* c = reinterpret_cast<float*>(smem_s);
+    c[threadIdx.x] = a.bias[threadIdx.x];
+    c[128 + threadIdx.x] = a.scale[threadIdx.x];
+    c[256 + threadIdx.x] = a.shift[threadIdx.x];
+  }
+  const int q = lane & 3, rsub = lane >> 2;
+
+  const GroupWalk gw = group_walk(a.ntiles, group);
+  const GroupWalk g0 = group_walk(a.ntiles, 0);
+  const int nphase = 2 * g0.count + 1;
+
+  // weight fragments: packed [tap][8 groups of 16 channels][2][128][8] bf16; scalar (tap, group) offset, one lane offset
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 9 * 128 * 128 * 2, 0x00020000);
+  const int wvoff = ((lh * 128) + wn * 64 + li) * 16;
+  uint4 bk[R][2];
+  auto load_bk = [&](uint4 (&dst)[2], int ks) {       // ks = chunk * 18 + tap * 2 + c
+    const int chunk = ks / 18, tap = (ks % 18) >> 1, c16 = chunk * 2 + (ks & 1);
+    const int soff = (tap * 8 + c16) * 4096;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + n * 512, soff, 0);
+      dst[n] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  };
+
+  uint4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int tile) {
+    const int gbase = tile * BM - W - 1;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 4, qq = idx & 15;
+      const int g = gbase + r;
+      const bool ok = r < rows && g >= 0 && g < a.M;
+      const size_t off = ok ? (size_t)g * 128 + 8 * qq : 0;
+      areg[k] = *reinterpret_cast<const uint4*>(in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto write_a = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      uint4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+      if ((idx >> 4) < rows) *reinterpret_cast<uint4*>(sA + ((idx >> 4) * S128_LDA + 8 * (idx & 15)) * 2) = v;
+    }
+  };
+
+  if (tid < S128_LDA * 2 / 16) *reinterpret_cast<uint4*>(sA + rows * S128_LDA * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
+  if (gw.count > 0) {
+    load_a(gw.first);
+    write_a();
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+  uint4 res[2][2][2];
+  for (int ph = 0; ph < nphase; ++ph) {
+    const int j = (ph - group) >> 1;
+    const bool mfma_phase = ((ph - group) & 1) == 0;
+    if (ph >= group && j < gw.count) {
+      const int t = gw.first + j * gw.step;
+      const int mw = t * BM + wm * 64;
+      if (mfma_phase) {
+#pragma unroll
+        for (int s0 = 0; s0 < R - 1; ++s0) load_bk(bk[s0], s0);
+        int arow[2][9];      // byte offset of the lane's operand row per tap; the zero row where padded
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned mk = border_mask(mw + i * 32 + li, a.M, H, W, a.mg_hw, a.mg_w);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+            arow[i][tap] = ((((mk >> tap) & 1u) ? wm * 64 + i * 32 + li + (tap / 3) * W + (tap % 3) : rows) * S128_LDA + 8 * lh) * 2;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+          if (ks + R - 1 < NK) load_bk(bk[(ks + R - 1) % R], ks + R - 1);
+          if (ks == NK - R + 1) {        // the last weight load of this tile has just been issued
+            if (j + 1 < gw.count) load_a(t + gw.step);
+            if (RES) {
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                  for (int k = 0; k < 2; ++k) {
+                    const int m = mw + i * 32 + 16 * k + rsub;
+                    const size_t off = m < a.M ? (size_t)m * 128 + wn * 64 + n * 32 + 8 * q : 0;
+                    res[i][n][k] = *reinterpret_cast<const uint4*>(resid + off);
+                  }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          const int chunk = ks / 18, tap = (ks % 18) >> 1, c16 = chunk * 2 + (ks & 1);
+          uint4 av[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const uint4*>(sA + arow[i][tap] + c16 * 32);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i]),
+                                                                  __builtin_bit_cast(bf16x8, bk[ks % R][n]), acc[i][n], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int co = wn * 64 + n * 32 + 8 * q;
+          const float4 cb0 = *reinterpret_cast<const float4*>(sC + co), cb1 = *reinterpret_cast<const float4*>(sC + co + 4);
+          const float4 cs0 = *reinterpret_cast<const float4*>(sC + 128 + co), cs1 = *reinterpret_cast<const float4*>(sC + 128 + co + 4);
+          const float4 ch0 = *reinterpret_cast<const float4*>(sC + 256 + co), ch1 = *reinterpret_cast<const float4*>(sC + 256 + co + 4);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][n][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const int row = 16 * k + rsub;
+              const int m = mw + i * 32 + row;
+              float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+              float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+              v.x = (v.x + cb0.x) * cs0.x + ch0.x; v.y = (v.y + cb0.y) * cs0.y + ch0.y;
+              v.z = (v.z + cb0.z) * cs0.z + ch0.z; v.w = (v.w + cb0.w) * cs0.w + ch0.w;
+              u.x = (u.x + cb1.x) * cs1.x + ch1.x; u.y = (u.y + cb1.y) * cs1.y + ch1.y;
+              u.z = (u.z + cb1.z) * cs1.z + ch1.z; u.w = (u.w + cb1.w) * cs1.w + ch1.w;
+              if (RES) {
+                const uint4 rr = res[i][n][k];
+                v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+                v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+                u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
+                u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
+              }
+              if (a.relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+              }
+              if (m < a.M)
+                *reinterpret_cast<uint4*>(out + (size_t)m * 128 + co) =
+                    make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y),
+                               thin_pack_bf16x2(u.z, u.w));
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+        if (j + 1 < gw.count) write_a();
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------- launch
 static int cu_count() {
   static int cached[64] = {0};
@@ -442,10 +640,15 @@ static bool thin64_shape(const ConvLayer& L, int w) {
   return L.taps == 9 && L.stride == 1 && L.cin_s == 64 && L.cout_s == 64 && L.cout_w == 64 && w <= W64_WMAX;
 }
 
+static bool stream128_shape(const ConvLayer& L, int w) {
+  static const int off = getenv("UMT_CONV_NOSTREAM128") ? 1 : 0;
+  return !off && L.taps == 9 && L.stride == 1 && L.cin_s == 128 && L.cout_s == 128 && L.cout_w == 128 && w <= S128_WMAX;
+}
+
 bool conv_thin_applicable(const ConvLayer& L, int w) {
   if (g_conv_thin < 0) g_conv_thin = getenv("UMT_CONV_NOTHIN") ? 0 : 1;     // A/B switch for profiling
   if (!g_conv_thin || L.taps != 9 || L.stride != 1) return false;
-  return (L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48) || thin64_shape(L, w);
+  return (L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48) || thin64_shape(L, w) || stream128_shape(L, w);
 }
 
 static int grid_for(int ntiles, int per_cu) {
@@ -472,7 +675,14 @@ static_assert((size_t)W64_WBYTES + W64_CBYTES + 2 * ((((size_t)(W64_BM + 2 * W64
                                                        4 * 32 * T_LDP * sizeof(float)) <= 160 * 1024,
               "conv3x3_wlds64_bf16: LDS budget");
 
+static unsigned char g_s128_lds_done[2][64];
+static size_t s128_lds_bytes(int w) {
+  return (size_t)S128_CBYTES + 2 * ((((size_t)(S128_BM + 2 * w + 2 + 1) * S128_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
+}
+
 int conv_thin_prepare_device() {      // largest request: W = 48
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<false>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[0]));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<true>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[1]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[0]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<true>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[1]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, false>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[0]));
@@ -489,6 +699,16 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
   ThinArgs a;
   a.in = in; a.w = L.wh; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift; a.residual = residual; a.out = out;
   a.H = h; a.W = w; a.M = (int)M; a.relu = L.relu;
+  if (stream128_shape(L, w)) {
+    a.ntiles = (int)((M + S128_BM - 1) / S128_BM);
+    a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+    a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
+    auto kern128 = residual ? conv3x3_stream128_bf16<true> : conv3x3_stream128_bf16<false>;
+    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern128), s128_lds_bytes(S128_WMAX), residual ? g_s128_lds_done[1] : g_s128_lds_done[0]));
+    hipLaunchKernelGGL(kern128, dim3(grid_for(a.ntiles, 1)), dim3(512), s128_lds_bytes(w), stream, a);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (thin64_shape(L, w)) {
     a.ntiles = (int)((M + W64_BM - 1) / W64_BM);
     a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
