@@ -34,5 +34,7 @@ for (name, fl), r in zip(L, seq):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
     kn = r["Kernel_Name"].replace("void umt::", "").split("(")[0]
-    print(f"{name:26s} {kn:34s} {d:9.1f} us {fl * n / d / 1e6:7.1f} TF vgpr {r['VGPR_Count']:>4s} lds {r['LDS_Block_Size']}")
+    # rocprofv3's VGPR_Count is half the kernel's register allocation per lane (.amdhsa_next_free_vgpr, accumulators
+    # included) on this toolchain; `regs` is the allocation that sets the waves per SIMD (512 / regs)
+    print(f"{name:26s} {kn:34s} {d:9.1f} us {fl * n / d / 1e6:7.1f} TF regs {2 * int(r['VGPR_Count']):>4d} lds {r['LDS_Block_Size']}")
 print(f"total {tot / 1e3:.3f} ms -> {sum(f for _, f in L) * n / tot / 1e6:.1f} TFLOP/s")
