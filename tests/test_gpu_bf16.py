@@ -102,9 +102,10 @@ def test_bf16_end_to_end_cost_on_golden_sequence(models, golden_sequence):
 
 
 def test_bf16_persistent_thin_kernel_bit_identical_to_halo_kernel(models, tmp_path):
-    """The 32-channel stage runs on the persistent kernel of conv_thin.hip; with UMT_CONV_NOTHIN=1 (read once
-    per process, hence the child process) it runs on conv3x3s1_halo_bf16.  Same arithmetic order, so the
-    backbone features must agree bit for bit, also for a crop count that leaves the last 256-pixel tile ragged."""
+    """Stages 1-3 run on the persistent kernels of conv_thin.hip (32 channels: weights in registers; 64: weights
+    in LDS; 128: weights streamed); with UMT_CONV_NOTHIN=1 (read once per process, hence the child process) they run
+    on conv3x3s1_halo_bf16.  Same arithmetic order, so the backbone features must agree bit for bit: for 7 crops
+    (fewer tiles than workgroups, ragged last tiles) and for 131 crops (several tiles per wave group, ragged)."""
     import os
     import subprocess
     import sys
@@ -118,14 +119,14 @@ def test_bf16_persistent_thin_kernel_bit_identical_to_halo_kernel(models, tmp_pa
         "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
         f"gm = model_from_state_dict(arch.make_synthetic_state({int(gm_seed(models))})).to('cuda')\n"
         "gm.precision = 'bf16'\n"
-        "img = torch.rand(7, 96, 96, generator=torch.Generator().manual_seed(31))\n"
-        f"np.save({str(out)!r}, gm.backbone(img.cuda()).cpu().numpy())\n")
+        "img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(31))\n"
+        f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:7].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()]))\n")
     env = dict(os.environ, UMT_CONV_NOTHIN="1")
     subprocess.run([sys.executable, "-c", child], check=True, env=env, timeout=110)
-    img = torch.rand(7, 96, 96, generator=torch.Generator().manual_seed(31))
+    img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(31))
     gm.precision = "bf16"
     try:
-        got = gm.backbone(img.cuda()).cpu().numpy()
+        got = np.concatenate([gm.backbone(img[:7].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()])
     finally:
         gm.precision = "fp32"
     assert np.array_equal(got, np.load(out))
