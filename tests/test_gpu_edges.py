@@ -135,3 +135,32 @@ def test_layer_timing_covers_every_backbone_launch():
     m.layer_timing_enable(True)
     assert m.layer_timing_read() == []
     m.layer_timing_enable(False)
+
+
+@pytest.mark.gpu
+def test_fp32_persistent_stage1_kernel_bit_identical_to_halo_kernel(tmp_path):
+    """fp32 mode, 32 -> 32 layers of stage 1: from 57 crops up they run on the persistent LDS-weights kernel of
+    conv_thin.hip (conv3x3_wlds32_f32); with UMT_CONV_NOTHIN_F32=1 (read once per process, hence the child process) on
+    conv3x3s1_halo_f32.  Same k order and epilogue arithmetic, so the backbone features must agree bit for bit; 131
+    crops leave the last 128-pixel tiles of the walk ragged, 57 is the switch-over size."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "halo.npy"
+    body = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from umetrack_amd import arch\n"
+        "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
+        "gm = model_from_state_dict(arch.make_synthetic_state(5)).to('cuda')\n"
+        "img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(77))\n"
+        "res = np.concatenate([gm.backbone(img[:57].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()])\n")
+    env = dict(os.environ, UMT_CONV_NOTHIN_F32="1")
+    subprocess.run([sys.executable, "-c", body + f"np.save({str(out)!r}, res)\n"], check=True, env=env, timeout=110)
+    gm = model_from_state_dict(arch.make_synthetic_state(5)).to("cuda")
+    img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(77))
+    got = np.concatenate([gm.backbone(img[:57].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()])
+    assert np.array_equal(got, np.load(out))

@@ -209,7 +209,8 @@ int main(int argc, char** argv) {
         if (bf) launch_conv_bf16(L, (const uint16_t*)in, n, sh.hw, sh.hw, sh.res ? (const uint16_t*)res : nullptr, out, 0, 0);
         else launch_conv(L, (const float*)in, n, sh.hw, sh.hw, sh.res ? (const float*)res : nullptr, (float*)out, 0);
       };
-      if (bf && (conv_thin_applicable(L, sh.hw) || g_conv_thin == 0)) {   // new kernel vs the one-tile-per-workgroup kernel
+      if ((bf && (conv_thin_applicable(L, sh.hw) || g_conv_thin == 0)) ||
+          (!bf && sh.cin == 32 && sh.cout == 32 && sh.taps == 9 && sh.stride == 1)) {   // new kernel vs the one-tile-per-workgroup kernel
         ConvLayer L2 = L;
         std::vector<unsigned char> r0(out_n * esz), r1(out_n * esz);
         g_conv_thin = 0; run(); hipDeviceSynchronize(); hipMemcpy(r0.data(), out, out_n * esz, hipMemcpyDeviceToHost);

@@ -507,6 +507,8 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   UMT_REQUIRE(L.cin_s % 8 == 0 && L.cout_s % 8 == 0 && L.cout_w % 32 == 0 && L.cout_s <= L.cout_w,
               UMT_ERR_INVALID, "conv: channel strides %d/%d/%d", L.cin_s, L.cout_s, L.cout_w);
   UMT_REQUIRE(n > 0 && h > 0 && w > 0, UMT_ERR_INVALID, "conv: empty input");
+  if (conv_thin_f32_applicable(L, w) && (int64_t)n * h * w >= 4 * 256 * 128)   // one tile per wave group and CU at least
+    return launch_conv_thin_f32(L, in, n, h, w, residual, out, stream);
   ConvArgs a;
   a.in = in; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift;
   a.residual = residual; a.out = out;

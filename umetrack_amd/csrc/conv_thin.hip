@@ -621,6 +621,152 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ fp32, 32 -> 32, weights in LDS
+// The four 32 -> 32 layers of stage 1 in the fp32 (reference-parity) mode, same two-group scheme.  On
+// conv3x3s1_halo_f32 they ran the matrix pipe 68 % busy (three waves per SIMD, each workgroup exposing its own halo
+// fetch, residual fetch and epilogue).  Here the packed weights (36.9 KB of fp32) sit in LDS, both operands of
+// every v_mfma_f32_32x32x2_f32 are ds_read_b128 (one A and one B fragment per four MFMAs), a tile's 144 MFMAs per
+// wave run without a barrier or a global load, and the other group's epilogue, residual and next halo range
+// overlap them.  k order (tap, 8-channel group, element) and the epilogue arithmetic are conv3x3s1_halo_f32's:
+// bit-identical results (tools/conv_bench.hip and tests/test_gpu_edges.py hold them so).
+constexpr int F32_LDA = 36;                    // floats per LDS row (144 B)
+constexpr int F32_BM = 128;
+constexpr int F32_WBYTES = 9 * 4 * 2 * 32 * 16;   // packed weights [9][4][2][32][4] fp32
+
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_wlds32_f32(ThinArgs a) {
+  constexpr int BM = F32_BM;
+  constexpr int NLD = ((BM + 2 * 48 + 2) * 8 + 255) / 256;   // float4 slots per thread for one halo range
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, group = threadIdx.x >> 8;
+  const int a_bytes = (rows + 1) * F32_LDA * 4;                  // halo range + the all-zero row (multiple of 16)
+  unsigned char* sW = smem_f;
+  unsigned char* sA = smem_f + F32_WBYTES + group * (a_bytes + 4 * 32 * F32_LDA * 4);
+  float* patch = reinterpret_cast<float*>(sA + a_bytes) + wave * 32 * F32_LDA;
+  const int li = lane & 31, lh = lane >> 5;
+  const float* in = reinterpret_cast<const float*>(a.in);
+  const float* resid = reinterpret_cast<const float*>(a.residual);
+  float* out = reinterpret_cast<float*>(a.out);
+
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+    for (int i = threadIdx.x; i < F32_WBYTES / 16; i += 512) *reinterpret_cast<uint4*>(sW + 16 * i) = wp[i];
+  }
+  // epilogue: a lane owns 4 consecutive channels of a pixel row, 8 rows per pass
+  const int q = lane & 7, rsub = lane >> 3;
+  const float4 cb = *reinterpret_cast<const float4*>(a.bias + 4 * q);
+  const float4 cs = *reinterpret_cast<const float4*>(a.scale + 4 * q);
+  const float4 ch = *reinterpret_cast<const float4*>(a.shift + 4 * q);
+
+  const GroupWalk gw = group_walk(a.ntiles, group);
+  const GroupWalk g0 = group_walk(a.ntiles, 0);
+  const int nphase = 2 * g0.count + 1;
+
+  float4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int tile) {
+    const int gbase = tile * BM - W - 1;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 3, qq = idx & 7;
+      const int g = gbase + r;
+      const bool ok = r < rows && g >= 0 && g < a.M;
+      const size_t off = ok ? (size_t)g * 32 + 4 * qq : 0;
+      areg[k] = *reinterpret_cast<const float4*>(in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto write_a = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      float4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + ((idx >> 3) * F32_LDA + 4 * (idx & 7)) * 4) = v;
+    }
+  };
+
+  if (tid < F32_LDA / 4) *reinterpret_cast<float4*>(sA + (rows * F32_LDA + 4 * tid) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (gw.count > 0) {
+    load_a(gw.first);
+    write_a();
+  }
+  __syncthreads();
+
+  f32x16 acc;
+  float4 res[4];
+  for (int ph = 0; ph < nphase; ++ph) {
+    const int j = (ph - group) >> 1;
+    const bool mfma_phase = ((ph - group) & 1) == 0;
+    if (ph >= group && j < gw.count) {
+      const int t = gw.first + j * gw.step;
+      const int mw = t * BM + wave * 32;
+      if (mfma_phase) {
+        if (j + 1 < gw.count) load_a(t + gw.step);
+        if (RES) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int m = mw + 8 * k + rsub;
+            const size_t off = m < a.M ? (size_t)m * 32 + 4 * q : 0;
+            res[k] = *reinterpret_cast<const float4*>(resid + off);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int arow[9];      // byte offset of the lane's operand row per tap; the zero row where padded
+        {
+          const unsigned mk = border_mask(mw + li, a.M, H, W, a.mg_hw, a.mg_w);
+#pragma unroll
+          for (int tap = 0; tap < 9; ++tap)
+            arow[tap] = ((((mk >> tap) & 1u) ? wave * 32 + li + (tap / 3) * W + (tap % 3) : rows) * F32_LDA + 4 * lh) * 4;
+        }
+        const unsigned char* bl = sW + (lh * 32 + li) * 16;      // + (tap * 4 + c8) * 1024
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float4 av = *reinterpret_cast<const float4*>(sA + arow[tap] + c * 32);
+            const float4 bv = *reinterpret_cast<const float4*>(bl + (tap * 4 + c) * 1024);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+          }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * F32_LDA + li] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = 8 * k + rsub;
+          const int m = mw + row;
+          float4 v = *reinterpret_cast<const float4*>(patch + row * F32_LDA + 4 * q);
+          v.x = (v.x + cb.x) * cs.x + ch.x;
+          v.y = (v.y + cb.y) * cs.y + ch.y;
+          v.z = (v.z + cb.z) * cs.z + ch.z;
+          v.w = (v.w + cb.w) * cs.w + ch.w;
+          if (RES) { v.x += res[k].x; v.y += res[k].y; v.z += res[k].z; v.w += res[k].w; }
+          if (a.relu) {      // max(v, 0) as one integer max on the bits, as conv_f32_common.h
+            v.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.x), 0));
+            v.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.y), 0));
+            v.z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.z), 0));
+            v.w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.w), 0));
+          }
+          if (m < a.M) *reinterpret_cast<float4*>(out + (size_t)m * 32 + 4 * q) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (j + 1 < gw.count) write_a();
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------- launch
 static int cu_count() {
   static int cached[64] = {0};
@@ -680,7 +826,39 @@ static size_t s128_lds_bytes(int w) {
   return (size_t)S128_CBYTES + 2 * ((((size_t)(S128_BM + 2 * w + 2 + 1) * S128_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
 
+static unsigned char g_f32_lds_done[2][64];
+static size_t f32_lds_bytes(int w) {
+  return (size_t)F32_WBYTES + 2 * ((size_t)(F32_BM + 2 * w + 2 + 1) * F32_LDA * 4 + 4 * 32 * F32_LDA * sizeof(float));
+}
+static_assert((size_t)F32_WBYTES + 2 * ((size_t)(F32_BM + 2 * 48 + 2 + 1) * F32_LDA * 4 + 4 * 32 * F32_LDA * sizeof(float)) <= 160 * 1024,
+              "conv3x3_wlds32_f32: LDS budget");
+
+bool conv_thin_f32_applicable(const ConvLayer& L, int w) {
+  static const int off = getenv("UMT_CONV_NOTHIN_F32") ? 1 : 0;     // A/B switch for profiling and the bit-identity test
+  return !off && g_conv_thin != 0 && L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48;
+}
+
+int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
+                         hipStream_t stream) {
+  const int64_t M = (int64_t)n * h * w;
+  UMT_REQUIRE(L.w, UMT_ERR_STATE, "conv_thin_f32: layer has no weights");
+  UMT_REQUIRE(M > 0 && M < ((int64_t)1 << 31) - 4096, UMT_ERR_INVALID, "conv_thin_f32: %lld pixels", (long long)M);
+  ThinArgs a;
+  a.in = in; a.w = L.w; a.bias = L.bias; a.scale = L.scale; a.shift = L.shift; a.residual = residual; a.out = out;
+  a.H = h; a.W = w; a.M = (int)M; a.relu = L.relu;
+  a.ntiles = (int)((M + F32_BM - 1) / F32_BM);
+  a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
+  a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
+  auto kern = residual ? conv3x3_wlds32_f32<true> : conv3x3_wlds32_f32<false>;
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), f32_lds_bytes(48), residual ? g_f32_lds_done[1] : g_f32_lds_done[0]));
+  hipLaunchKernelGGL(kern, dim3(grid_for(a.ntiles, 1)), dim3(512), f32_lds_bytes(w), stream, a);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 int conv_thin_prepare_device() {      // largest request: W = 48
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<false>), f32_lds_bytes(48), g_f32_lds_done[0]));
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<true>), f32_lds_bytes(48), g_f32_lds_done[1]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<false>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[0]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<true>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[1]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[0]));

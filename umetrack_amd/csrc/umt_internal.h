@@ -124,6 +124,11 @@ bool conv_thin_applicable(const ConvLayer& L, int w);
 int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual,
                           uint16_t* out, hipStream_t stream);
 
+// conv_thin.hip: persistent fp32 kernel for the 32->32 stride-1 3x3 layers (weights in LDS), bit-identical to the halo kernel
+bool conv_thin_f32_applicable(const ConvLayer& L, int w);
+int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
+                         hipStream_t stream);
+
 // stem.hip: conv3x3(1->32)+bias+BN+ReLU+maxpool2 ; images (n,96,96) -> rows [n*48*48][32]
 struct StemParams {
   const float* w;      // dev [9][32]
