@@ -102,8 +102,8 @@ def test_bf16_end_to_end_cost_on_golden_sequence(models, golden_sequence):
 
 
 def test_bf16_persistent_thin_kernel_bit_identical_to_halo_kernel(models, tmp_path):
-    """Stages 1-3 run on the persistent kernels of conv_thin.hip (32 channels: weights in registers; 64: weights
-    in LDS; 128: weights streamed); with UMT_CONV_NOTHIN=1 (read once per process, hence the child process) they run
+    """Stages 1-3 run on the persistent kernels of conv_thin.hip (stage 1: each BasicBlock fused into one launch with
+    the intermediate rows in LDS; 64 channels: weights in LDS; 128: weights streamed); with UMT_CONV_NOTHIN=1 (read once per process, hence the child process) they run
     on conv3x3s1_halo_bf16.  Same arithmetic order, so the backbone features must agree bit for bit: for 7 crops
     (fewer tiles than workgroups, ragged last tiles) and for 131 crops (several tiles per wave group, ragged)."""
     import os

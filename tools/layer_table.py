@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-ks = [r for r in rows if "conv" in r["Kernel_Name"] or "stem" in r["Kernel_Name"]]
+ks = [r for r in rows if "conv" in r["Kernel_Name"] or "stem" in r["Kernel_Name"] or "block32_fused" in r["Kernel_Name"]]
 ks.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(ks) if "stem" in r["Kernel_Name"]]
 seq = ks[idx[-1]:]
@@ -30,7 +30,16 @@ for cin, cout, st, nb in [(32, 32, 1, 2), (32, 64, 2, 3), (64, 128, 2, 5), (128,
         L.append((f"c2 {cout}->{cout} hw{hw}", conv(cout, cout, hw, 3)))
 L.append(("proj", conv(256, 72, 6, 1)))
 tot = 0
-for (name, fl), r in zip(L, seq):
+li = 0
+for r in seq:
+    if li >= len(L):
+        break
+    name, fl = L[li]
+    li += 1
+    if "block32_fused" in r["Kernel_Name"]:      # conv1 + conv2 of a stage-1 block in one launch (bf16 mode)
+        n2, f2 = L[li]
+        li += 1
+        name, fl = "c1+c2 32->32 hw48 (fused)", fl + f2
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
     kn = r["Kernel_Name"].replace("void umt::", "").split("(")[0]

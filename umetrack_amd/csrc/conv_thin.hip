@@ -767,6 +767,244 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds32_f32(ThinArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ bf16, fused BasicBlock 32 -> 32 -> 32
+// A whole stage-1 BasicBlock (lib/models/backbone_resnet.py:56-72, planes = 32, stride 1: conv1 + BN + ReLU, conv2 + BN +
+// residual + ReLU) in one kernel, UMT_PREC_BF16.  Unfused, a block moves 735 KB per crop through HBM (conv1 reads x and
+// writes t; conv2 reads t and x and writes y) and both launches are HBM-bound; here the workgroup keeps t on chip:
+//   * a tile is eight output rows of one 48x48 image; the workgroup stages the twelve input rows around it (576 pixels,
+//     rows outside the image as zeros), computes the ten rows of t that conv2 needs (480 pixels: 1.25x the tile, the
+//     price of not exchanging halo rows between workgroups) into LDS as bf16 - rounded exactly as the unfused
+//     kernel rounds them for HBM - and then the four output rows, taking the residual from the staged input;
+//   * x is read once (1.3-2x with the halo rows, which neighbouring tiles on the same XCD share through L2) and y
+//     written once: about 300-440 KB per crop and block;
+//   * both weight tensors (2 x 18.4 KB) sit in LDS: with them in registers (2 x 72 per lane) the compiler had none
+//     left to read operands ahead of the MFMAs, and the kernel ran at half the speed of the two separate launches;
+//     one persistent 512-thread workgroup per CU (158 KB of LDS), the next tile's input rows prefetched into registers.
+// k order (tap, 16-channel group) and epilogue arithmetic are those of conv3x3_thin32_bf16 / conv3x3s1_halo_bf16, and
+// t rows outside the image are zeros as conv2's padding requires: bit-identical to the two separate launches.
+constexpr int FB_W = 48, FB_H = 48, FB_R = 8;              // image size and output rows per tile
+constexpr int FB_XPIX = (FB_R + 4) * FB_W;                 // 576 staged input pixels
+constexpr int FB_TPIX = (FB_R + 2) * FB_W;                 // 480 intermediate pixels
+constexpr int FB_OPIX = FB_R * FB_W;                       // 384 output pixels
+constexpr int FB_XBYTES = (FB_XPIX + 1) * T_LDH * 2;       // + the all-zero row
+constexpr int FB_TBYTES = (FB_TPIX + 1) * T_LDH * 2;
+constexpr int FB_WBYTES = 9 * 2 * 2 * 32 * 16;             // one packed weight tensor
+constexpr int FB_LDS = FB_XBYTES + FB_TBYTES + 8 * 32 * T_LDP * 4 + 2 * FB_WBYTES;
+static_assert(FB_LDS <= 160 * 1024, "block32_fused_bf16: LDS budget");
+
+struct FusedBlockArgs {
+  const uint16_t* in;      // rows [n*48*48][32] bf16
+  const uint16_t* w1;      // packed [9][2][2][32][8] bf16
+  const uint16_t* w2;
+  const float *bias1, *scale1, *shift1;
+  const float *bias2, *scale2, *shift2;
+  uint16_t* out;           // rows [n*48*48][32] bf16
+  int ntiles;              // n * 6
+};
+
+__global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
+  constexpr int NLD = (FB_XPIX * 4 + 511) / 512;      // 5 uint4 per thread for one input range
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* sX = smem_b;
+  unsigned char* sT = smem_b + FB_XBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* patch = reinterpret_cast<float*>(smem_b + FB_XBYTES + FB_TBYTES) + wave * 32 * T_LDP;
+  unsigned char* sW1 = smem_b + FB_XBYTES + FB_TBYTES + 8 * 32 * T_LDP * 4;
+  unsigned char* sW2 = sW1 + FB_WBYTES;
+  const int li = lane & 31, lh = lane >> 5;
+  const int q = lane & 3, rsub = lane >> 2;
+
+  for (int i = tid; i < FB_WBYTES / 16; i += 512) {
+    *reinterpret_cast<uint4*>(sW1 + 16 * i) = reinterpret_cast<const uint4*>(a.w1)[i];
+    *reinterpret_cast<uint4*>(sW2 + 16 * i) = reinterpret_cast<const uint4*>(a.w2)[i];
+  }
+  const int boff = (lh * 32 + li) * 16;        // + (tap * 2 + c) * 1024
+
+  int T, tstep, tend;
+  tile_walk(a.ntiles, T, tstep, tend);
+
+  uint4 areg[NLD];
+  unsigned aok = 0;
+  auto load_x = [&](int tile) {
+    const int img = tile / (FB_H / FB_R), y0 = (tile - img * (FB_H / FB_R)) * FB_R;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 512 * k;
+      const int px = idx >> 2, qq = idx & 3;
+      const int xr = px / FB_W;
+      const int y = y0 - 2 + xr;
+      const bool ok = px < FB_XPIX && y >= 0 && y < FB_H;
+      const size_t off = ok ? ((size_t)(img * FB_H + y0 - 2) * FB_W + px) * 32 + 8 * qq : 0;
+      areg[k] = *reinterpret_cast<const uint4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  auto write_x = [&]() {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 512 * k;
+      uint4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+      if ((idx >> 2) < FB_XPIX) *reinterpret_cast<uint4*>(sX + ((idx >> 2) * T_LDH + 8 * (idx & 3)) * 2) = v;
+    }
+  };
+
+  if (tid < T_LDH * 2 / 16) {
+    *reinterpret_cast<uint4*>(sX + FB_XPIX * T_LDH * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(sT + FB_TPIX * T_LDH * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
+  }
+  if (T < tend) {
+    load_x(T);
+    write_x();
+  }
+  __syncthreads();
+
+  for (; T < tend; T += tstep) {
+    const int img = T / (FB_H / FB_R), y0 = (T - img * (FB_H / FB_R)) * FB_R;
+    const bool has_next = T + tstep < tend;
+    if (has_next) load_x(T + tstep);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- conv1: 15 tiles of 32 intermediate pixels; wave w takes w and w+8 TOGETHER (one weight read feeds both)
+    // (epilogue constants - a lane owns channels 8q..8q+7 - are re-read per phase: registers are what is scarce here)
+    {
+      const float4 pb0 = *reinterpret_cast<const float4*>(a.bias1 + 8 * q), pb1 = *reinterpret_cast<const float4*>(a.bias1 + 8 * q + 4);
+      const float4 ps0 = *reinterpret_cast<const float4*>(a.scale1 + 8 * q), ps1 = *reinterpret_cast<const float4*>(a.scale1 + 8 * q + 4);
+      const float4 ph0 = *reinterpret_cast<const float4*>(a.shift1 + 8 * q), ph1 = *reinterpret_cast<const float4*>(a.shift1 + 8 * q + 4);
+      const int kt[2] = {wave, wave + 8};
+      const bool two = kt[1] < FB_TPIX / 32;
+      int arow[2][9];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = (i == 0 || two ? kt[i] : kt[0]) * 32 + li;
+        const int tr = f / FB_W, col = f - tr * FB_W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          const int xx = col + kx - 1;
+          const bool ok = xx >= 0 && xx < FB_W;
+          arow[i][tap] = ((ok ? (tr + ky) * FB_W + xx : FB_XPIX) * T_LDH + 8 * lh) * 2;
+        }
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint4 bw = *reinterpret_cast<const uint4*>(sW1 + boff + (tap * 2 + c) * 1024);
+          const uint4 r0 = *reinterpret_cast<const uint4*>(sX + arow[0][tap] + c * 32);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
+          if (two) {
+            const uint4 r1 = *reinterpret_cast<const uint4*>(sX + arow[1][tap] + c * 32);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !two) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = 16 * k + rsub;
+          const int ff = kt[i] * 32 + row;
+          const int yt = y0 - 1 + ff / FB_W;            // image row of this intermediate pixel
+          float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+          float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+          v.x = (v.x + pb0.x) * ps0.x + ph0.x; v.y = (v.y + pb0.y) * ps0.y + ph0.y;
+          v.z = (v.z + pb0.z) * ps0.z + ph0.z; v.w = (v.w + pb0.w) * ps0.w + ph0.w;
+          u.x = (u.x + pb1.x) * ps1.x + ph1.x; u.y = (u.y + pb1.y) * ps1.y + ph1.y;
+          u.z = (u.z + pb1.z) * ps1.z + ph1.z; u.w = (u.w + pb1.w) * ps1.w + ph1.w;
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+          uint4 o = make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y), thin_pack_bf16x2(u.z, u.w));
+          if (yt < 0 || yt >= FB_H) o = make_uint4(0, 0, 0, 0);     // conv2's zero padding above and below the image
+          *reinterpret_cast<uint4*>(sT + (ff * T_LDH + 8 * q) * 2) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+
+    // ---- conv2: 12 tiles of 32 output pixels; wave w takes (w+1)%8 and, for four of the waves, that + 8 (wave 7 had one conv1 tile)
+    {
+      const float4 pb0 = *reinterpret_cast<const float4*>(a.bias2 + 8 * q), pb1 = *reinterpret_cast<const float4*>(a.bias2 + 8 * q + 4);
+      const float4 ps0 = *reinterpret_cast<const float4*>(a.scale2 + 8 * q), ps1 = *reinterpret_cast<const float4*>(a.scale2 + 8 * q + 4);
+      const float4 ph0 = *reinterpret_cast<const float4*>(a.shift2 + 8 * q), ph1 = *reinterpret_cast<const float4*>(a.shift2 + 8 * q + 4);
+      const int kt[2] = {(wave + 1) & 7, ((wave + 1) & 7) + 8};
+      const bool two = kt[1] < FB_OPIX / 32;
+      int arow[2][9];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int f = (i == 0 || two ? kt[i] : kt[0]) * 32 + li;
+        const int orow = f / FB_W, col = f - orow * FB_W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          const int xx = col + kx - 1;
+          const bool ok = xx >= 0 && xx < FB_W;
+          arow[i][tap] = ((ok ? (orow + ky) * FB_W + xx : FB_TPIX) * T_LDH + 8 * lh) * 2;
+        }
+      }
+      f32x16 acc[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const uint4 bw = *reinterpret_cast<const uint4*>(sW2 + boff + (tap * 2 + c) * 1024);
+          const uint4 r0 = *reinterpret_cast<const uint4*>(sT + arow[0][tap] + c * 32);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
+          if (two) {
+            const uint4 r1 = *reinterpret_cast<const uint4*>(sT + arow[1][tap] + c * 32);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (i == 1 && !two) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = 16 * k + rsub;
+          const int ff = kt[i] * 32 + row;                    // output pixel within the tile
+          float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+          float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+          v.x = (v.x + pb0.x) * ps0.x + ph0.x; v.y = (v.y + pb0.y) * ps0.y + ph0.y;
+          v.z = (v.z + pb0.z) * ps0.z + ph0.z; v.w = (v.w + pb0.w) * ps0.w + ph0.w;
+          u.x = (u.x + pb1.x) * ps1.x + ph1.x; u.y = (u.y + pb1.y) * ps1.y + ph1.y;
+          u.z = (u.z + pb1.z) * ps1.z + ph1.z; u.w = (u.w + pb1.w) * ps1.w + ph1.w;
+          const uint4 rr = *reinterpret_cast<const uint4*>(sX + ((ff + 2 * FB_W) * T_LDH + 8 * q) * 2);   // the block input
+          v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+          u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
+          u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+          const size_t gp = (size_t)(img * FB_H + y0) * FB_W + ff;
+          *reinterpret_cast<uint4*>(a.out + gp * 32 + 8 * q) =
+              make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y), thin_pack_bf16x2(u.z, u.w));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();          // every wave is done with sX and sT
+    if (has_next) write_x();
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------------------- launch
 static int cu_count() {
   static int cached[64] = {0};
@@ -826,6 +1064,30 @@ static size_t s128_lds_bytes(int w) {
   return (size_t)S128_CBYTES + 2 * ((((size_t)(S128_BM + 2 * w + 2 + 1) * S128_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
 
+static unsigned char g_fb_lds_done[64];
+bool block32_fused_applicable(const ConvLayer& c1, const ConvLayer& c2, int h, int w) {
+  static const int off = getenv("UMT_CONV_NOFUSE") ? 1 : 0;      // A/B switch for profiling and the bit-identity test
+  if (g_conv_thin < 0) g_conv_thin = getenv("UMT_CONV_NOTHIN") ? 0 : 1;
+  auto ok = [](const ConvLayer& L) {
+    return L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && L.wh != nullptr;
+  };
+  return !off && g_conv_thin && h == FB_H && w == FB_W && ok(c1) && ok(c2) && c1.relu && c2.relu;
+}
+
+int launch_block32_fused_bf16(const ConvLayer& c1, const ConvLayer& c2, const uint16_t* in, int n, uint16_t* out,
+                              hipStream_t stream) {
+  UMT_REQUIRE(block32_fused_applicable(c1, c2, FB_H, FB_W) && n > 0 && n < (1 << 20), UMT_ERR_INVALID, "block32_fused: bad arguments");
+  FusedBlockArgs a;
+  a.in = in; a.w1 = c1.wh; a.w2 = c2.wh; a.out = out;
+  a.bias1 = c1.bias; a.scale1 = c1.scale; a.shift1 = c1.shift;
+  a.bias2 = c2.bias; a.scale2 = c2.scale; a.shift2 = c2.shift;
+  a.ntiles = n * (FB_H / FB_R);
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(block32_fused_bf16), FB_LDS, g_fb_lds_done));
+  hipLaunchKernelGGL(block32_fused_bf16, dim3(grid_for(a.ntiles, 1)), dim3(512), FB_LDS, stream, a);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static unsigned char g_f32_lds_done[2][64];
 static size_t f32_lds_bytes(int w) {
   return (size_t)F32_WBYTES + 2 * ((size_t)(F32_BM + 2 * w + 2 + 1) * F32_LDA * 4 + 4 * 32 * F32_LDA * sizeof(float));
@@ -857,6 +1119,7 @@ int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int 
 }
 
 int conv_thin_prepare_device() {      // largest request: W = 48
+  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(block32_fused_bf16), FB_LDS, g_fb_lds_done));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<false>), f32_lds_bytes(48), g_f32_lds_done[0]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<true>), f32_lds_bytes(48), g_f32_lds_done[1]));
   UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<false>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[0]));

@@ -467,6 +467,18 @@ static int run_blocks_bf16(umt_model* m, size_t b0, size_t b1, int n, uint16_t*&
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
     const uint16_t* res = x;
+    if (!B.has_down && block32_fused_applicable(B.conv1, B.conv2, hw, hw)) {     // conv1 -> conv2 (+x) with t kept on chip
+      UMT_TRY(launch_block32_fused_bf16(B.conv1, B.conv2, x, n, y, s));
+      if (m->layer_timing) {
+        char nm[48];
+        snprintf(nm, sizeof(nm), "c1+c2+res %d->%d hw%d s1", B.conv1.cin, B.conv2.cout, hw);
+        UMT_TRY(layer_mark(m, s, nm, 2.0 * 2.0 * 9 * B.conv1.cin * B.conv1.cout * (double)n * hw * hw));
+      }
+      uint16_t* old = x;
+      x = y;
+      y = old;
+      continue;
+    }
     if (B.has_down && conv_s2_fused_applicable(B.conv1, &B.down, hw, hw)) {
       UMT_TRY(launch_conv_s2_fused_bf16(B.conv1, &B.down, x, n, hw, hw, t, d, s));
       UMT_TRY(conv_mark(m, s, "c1+ds", B.conv1, &B.down, n, hw));

@@ -129,6 +129,11 @@ bool conv_thin_f32_applicable(const ConvLayer& L, int w);
 int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
                          hipStream_t stream);
 
+// conv_thin.hip: a whole 32-channel BasicBlock of stage 1 in one bf16 kernel (intermediate rows stay in LDS)
+bool block32_fused_applicable(const ConvLayer& c1, const ConvLayer& c2, int h, int w);
+int launch_block32_fused_bf16(const ConvLayer& c1, const ConvLayer& c2, const uint16_t* in, int n, uint16_t* out,
+                              hipStream_t stream);
+
 // stem.hip: conv3x3(1->32)+bias+BN+ReLU+maxpool2 ; images (n,96,96) -> rows [n*48*48][32]
 struct StemParams {
   const float* w;      // dev [9][32]
