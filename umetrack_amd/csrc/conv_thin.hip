@@ -21,6 +21,7 @@
 // prefetch registers, and measured 7 % faster without and 3 % slower with a residual.
 #include "umt_internal.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace umt {
 
@@ -866,12 +867,18 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
     if (has_next) load_x(T + tstep);
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- conv1: 15 tiles of 32 intermediate pixels; wave w takes w and w+8 TOGETHER (one weight read feeds both)
-    // (epilogue constants - a lane owns channels 8q..8q+7 - are re-read per phase: registers are what is scarce here)
+    // ---- conv1: 15 tiles of 32 intermediate pixels; wave w takes w and w+8 TOGETHER (one weight read feeds both).
+    // The MFMA operands are swapped (weights as the row operand, pixels as the column operand: the same two fragments,
+    // the other way round), so the accumulator is t TRANSPOSED: a lane owns one pixel and the 16 channels
+    // 8g + 4*lh + e.  Its BN + ReLU result goes to the pixel's LDS row as four 8-byte stores - no transposing patch.
     {
-      const float4 pb0 = *reinterpret_cast<const float4*>(a.bias1 + 8 * q), pb1 = *reinterpret_cast<const float4*>(a.bias1 + 8 * q + 4);
-      const float4 ps0 = *reinterpret_cast<const float4*>(a.scale1 + 8 * q), ps1 = *reinterpret_cast<const float4*>(a.scale1 + 8 * q + 4);
-      const float4 ph0 = *reinterpret_cast<const float4*>(a.shift1 + 8 * q), ph1 = *reinterpret_cast<const float4*>(a.shift1 + 8 * q + 4);
+      float4 pb[4], ps[4], ph[4];       // constants of the lane's channels, re-read per phase (registers are scarce)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pb[g] = *reinterpret_cast<const float4*>(a.bias1 + 8 * g + 4 * lh);
+        ps[g] = *reinterpret_cast<const float4*>(a.scale1 + 8 * g + 4 * lh);
+        ph[g] = *reinterpret_cast<const float4*>(a.shift1 + 8 * g + 4 * lh);
+      }
       const int kt[2] = {wave, wave + 8};
       const bool two = kt[1] < FB_TPIX / 32;
       int arow[2][9];
@@ -892,42 +899,40 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      auto taps1 = [&](auto twoc) {        // two straight-line bodies: a branch inside the tap loop would pin the schedule
+        constexpr bool TWO = decltype(twoc)::value;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint4 bw = *reinterpret_cast<const uint4*>(sW1 + boff + (tap * 2 + c) * 1024);
-          const uint4 r0 = *reinterpret_cast<const uint4*>(sX + arow[0][tap] + c * 32);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
-          if (two) {
-            const uint4 r1 = *reinterpret_cast<const uint4*>(sX + arow[1][tap] + c * 32);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) {
+            const uint4 bw = *reinterpret_cast<const uint4*>(sW1 + boff + (tap * 2 + c) * 1024);
+            const uint4 r0 = *reinterpret_cast<const uint4*>(sX + arow[0][tap] + c * 32);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r0), acc[0], 0, 0, 0);
+            if (TWO) {
+              const uint4 r1 = *reinterpret_cast<const uint4*>(sX + arow[1][tap] + c * 32);
+              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r1), acc[1], 0, 0, 0);
+            }
           }
-        }
+      };
+      if (two) taps1(std::true_type{});
+      else taps1(std::false_type{});
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (i == 1 && !two) break;
+        const int ff = kt[i] * 32 + li;
+        const int yt = y0 - 1 + ff / FB_W;              // image row of this intermediate pixel
+        const bool pad = yt < 0 || yt >= FB_H;           // conv2's zero padding above and below the image
 #pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int row = 16 * k + rsub;
-          const int ff = kt[i] * 32 + row;
-          const int yt = y0 - 1 + ff / FB_W;            // image row of this intermediate pixel
-          float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
-          float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
-          v.x = (v.x + pb0.x) * ps0.x + ph0.x; v.y = (v.y + pb0.y) * ps0.y + ph0.y;
-          v.z = (v.z + pb0.z) * ps0.z + ph0.z; v.w = (v.w + pb0.w) * ps0.w + ph0.w;
-          u.x = (u.x + pb1.x) * ps1.x + ph1.x; u.y = (u.y + pb1.y) * ps1.y + ph1.y;
-          u.z = (u.z + pb1.z) * ps1.z + ph1.z; u.w = (u.w + pb1.w) * ps1.w + ph1.w;
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
-          uint4 o = make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y), thin_pack_bf16x2(u.z, u.w));
-          if (yt < 0 || yt >= FB_H) o = make_uint4(0, 0, 0, 0);     // conv2's zero padding above and below the image
-          *reinterpret_cast<uint4*>(sT + (ff * T_LDH + 8 * q) * 2) = o;
+        for (int g = 0; g < 4; ++g) {
+          float v0 = (acc[i][4 * g + 0] + pb[g].x) * ps[g].x + ph[g].x;
+          float v1 = (acc[i][4 * g + 1] + pb[g].y) * ps[g].y + ph[g].y;
+          float v2 = (acc[i][4 * g + 2] + pb[g].z) * ps[g].z + ph[g].z;
+          float v3 = (acc[i][4 * g + 3] + pb[g].w) * ps[g].w + ph[g].w;
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          uint2 o = make_uint2(thin_pack_bf16x2(v0, v1), thin_pack_bf16x2(v2, v3));
+          if (pad) o = make_uint2(0, 0);
+          *reinterpret_cast<uint2*>(sT + (ff * T_LDH + 8 * g + 4 * lh) * 2) = o;
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
     __syncthreads();
@@ -957,18 +962,23 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      auto taps2 = [&](auto twoc) {
+        constexpr bool TWO = decltype(twoc)::value;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
+        for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const uint4 bw = *reinterpret_cast<const uint4*>(sW2 + boff + (tap * 2 + c) * 1024);
-          const uint4 r0 = *reinterpret_cast<const uint4*>(sT + arow[0][tap] + c * 32);
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
-          if (two) {
-            const uint4 r1 = *reinterpret_cast<const uint4*>(sT + arow[1][tap] + c * 32);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+          for (int c = 0; c < 2; ++c) {
+            const uint4 bw = *reinterpret_cast<const uint4*>(sW2 + boff + (tap * 2 + c) * 1024);
+            const uint4 r0 = *reinterpret_cast<const uint4*>(sT + arow[0][tap] + c * 32);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
+            if (TWO) {
+              const uint4 r1 = *reinterpret_cast<const uint4*>(sT + arow[1][tap] + c * 32);
+              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+            }
           }
-        }
+      };
+      if (two) taps2(std::true_type{});
+      else taps2(std::false_type{});
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (i == 1 && !two) break;
