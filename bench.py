@@ -423,6 +423,7 @@ def main():
                                   "h2d_GBs": rate, "frame_bytes_per_step": frame_bytes,
                                   "note": "step time plus an un-overlapped pinned host->device copy of the step's source "
                                           "frames at the measured rate; `value` above has the frames resident in HBM"}
+    if not args.no_pcie and world == 1:     # (single process only: pipe.step() ends in the all-reduce, and the other ranks are gone)
         # measured, not estimated: the next step's frames are copied from pinned host memory on a second stream into a
         # second device buffer while this step computes (what a reader feeding the GPU over PCIe would do)
         ov_steps = 3
