@@ -780,7 +780,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds32_f32(ThinArgs a) {
 //     written once: about 300-440 KB per crop and block;
 //   * both weight tensors (2 x 18.4 KB) sit in LDS: with them in registers (2 x 72 per lane) the compiler had none
 //     left to read operands ahead of the MFMAs, and the kernel ran at half the speed of the two separate launches;
-//     one persistent 512-thread workgroup per CU (158 KB of LDS), the next tile's input rows prefetched into registers.
+//     one persistent 512-thread workgroup per CU (122 KB of LDS), the next tile's input rows prefetched into registers;
+//   * both convolutions run with the MFMA operands swapped (weights as the row operand), so a lane owns a pixel's
+//     channels and neither epilogue needs the fp32 transposing patch of the other kernels.
 // k order (tap, 16-channel group) and epilogue arithmetic are those of conv3x3_thin32_bf16 / conv3x3s1_halo_bf16, and
 // t rows outside the image are zeros as conv2's padding requires: bit-identical to the two separate launches.
 constexpr int FB_W = 48, FB_H = 48, FB_R = 8;              // image size and output rows per tile
@@ -790,7 +792,7 @@ constexpr int FB_OPIX = FB_R * FB_W;                       // 384 output pixels
 constexpr int FB_XBYTES = (FB_XPIX + 1) * T_LDH * 2;       // + the all-zero row
 constexpr int FB_TBYTES = (FB_TPIX + 1) * T_LDH * 2;
 constexpr int FB_WBYTES = 9 * 2 * 2 * 32 * 16;             // one packed weight tensor
-constexpr int FB_LDS = FB_XBYTES + FB_TBYTES + 8 * 32 * T_LDP * 4 + 2 * FB_WBYTES;
+constexpr int FB_LDS = FB_XBYTES + FB_TBYTES + 2 * FB_WBYTES;
 static_assert(FB_LDS <= 160 * 1024, "block32_fused_bf16: LDS budget");
 
 struct FusedBlockArgs {
@@ -809,11 +811,9 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
   unsigned char* sX = smem_b;
   unsigned char* sT = smem_b + FB_XBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* patch = reinterpret_cast<float*>(smem_b + FB_XBYTES + FB_TBYTES) + wave * 32 * T_LDP;
-  unsigned char* sW1 = smem_b + FB_XBYTES + FB_TBYTES + 8 * 32 * T_LDP * 4;
+  unsigned char* sW1 = smem_b + FB_XBYTES + FB_TBYTES;
   unsigned char* sW2 = sW1 + FB_WBYTES;
   const int li = lane & 31, lh = lane >> 5;
-  const int q = lane & 3, rsub = lane >> 2;
 
   for (int i = tid; i < FB_WBYTES / 16; i += 512) {
     *reinterpret_cast<uint4*>(sW1 + 16 * i) = reinterpret_cast<const uint4*>(a.w1)[i];
@@ -937,11 +937,17 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
     }
     __syncthreads();
 
-    // ---- conv2: 12 tiles of 32 output pixels; wave w takes (w+1)%8 and, for four of the waves, that + 8 (wave 7 had one conv1 tile)
+    // ---- conv2: 12 tiles of 32 output pixels; wave w takes (w+1)%8 and, for four of the waves, that + 8 (wave 7 had
+    // one conv1 tile).  Operands swapped as in conv1: a lane owns one output pixel and the channels 8g + 4*lh + e, adds
+    // the residual from the pixel's staged input row and stores four 8-byte pieces of the pixel's 64-byte row.
     {
-      const float4 pb0 = *reinterpret_cast<const float4*>(a.bias2 + 8 * q), pb1 = *reinterpret_cast<const float4*>(a.bias2 + 8 * q + 4);
-      const float4 ps0 = *reinterpret_cast<const float4*>(a.scale2 + 8 * q), ps1 = *reinterpret_cast<const float4*>(a.scale2 + 8 * q + 4);
-      const float4 ph0 = *reinterpret_cast<const float4*>(a.shift2 + 8 * q), ph1 = *reinterpret_cast<const float4*>(a.shift2 + 8 * q + 4);
+      float4 pb[4], ps[4], ph[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        pb[g] = *reinterpret_cast<const float4*>(a.bias2 + 8 * g + 4 * lh);
+        ps[g] = *reinterpret_cast<const float4*>(a.scale2 + 8 * g + 4 * lh);
+        ph[g] = *reinterpret_cast<const float4*>(a.shift2 + 8 * g + 4 * lh);
+      }
       const int kt[2] = {(wave + 1) & 7, ((wave + 1) & 7) + 8};
       const bool two = kt[1] < FB_OPIX / 32;
       int arow[2][9];
@@ -970,10 +976,10 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
           for (int c = 0; c < 2; ++c) {
             const uint4 bw = *reinterpret_cast<const uint4*>(sW2 + boff + (tap * 2 + c) * 1024);
             const uint4 r0 = *reinterpret_cast<const uint4*>(sT + arow[0][tap] + c * 32);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r0), __builtin_bit_cast(bf16x8, bw), acc[0], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r0), acc[0], 0, 0, 0);
             if (TWO) {
               const uint4 r1 = *reinterpret_cast<const uint4*>(sT + arow[1][tap] + c * 32);
-              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, r1), __builtin_bit_cast(bf16x8, bw), acc[1], 0, 0, 0);
+              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r1), acc[1], 0, 0, 0);
             }
           }
       };
@@ -982,31 +988,20 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (i == 1 && !two) break;
+        const int ff = kt[i] * 32 + li;                        // output pixel within the tile
+        const size_t gp = (size_t)(img * FB_H + y0) * FB_W + ff;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][r];
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int row = 16 * k + rsub;
-          const int ff = kt[i] * 32 + row;                    // output pixel within the tile
-          float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
-          float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
-          v.x = (v.x + pb0.x) * ps0.x + ph0.x; v.y = (v.y + pb0.y) * ps0.y + ph0.y;
-          v.z = (v.z + pb0.z) * ps0.z + ph0.z; v.w = (v.w + pb0.w) * ps0.w + ph0.w;
-          u.x = (u.x + pb1.x) * ps1.x + ph1.x; u.y = (u.y + pb1.y) * ps1.y + ph1.y;
-          u.z = (u.z + pb1.z) * ps1.z + ph1.z; u.w = (u.w + pb1.w) * ps1.w + ph1.w;
-          const uint4 rr = *reinterpret_cast<const uint4*>(sX + ((ff + 2 * FB_W) * T_LDH + 8 * q) * 2);   // the block input
-          v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
-          v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
-          u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
-          u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-          u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
-          const size_t gp = (size_t)(img * FB_H + y0) * FB_W + ff;
-          *reinterpret_cast<uint4*>(a.out + gp * 32 + 8 * q) =
-              make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y), thin_pack_bf16x2(u.z, u.w));
+        for (int g = 0; g < 4; ++g) {
+          const uint2 rr = *reinterpret_cast<const uint2*>(sX + ((ff + 2 * FB_W) * T_LDH + 8 * g + 4 * lh) * 2);   // the block input
+          float v0 = (acc[i][4 * g + 0] + pb[g].x) * ps[g].x + ph[g].x;
+          float v1 = (acc[i][4 * g + 1] + pb[g].y) * ps[g].y + ph[g].y;
+          float v2 = (acc[i][4 * g + 2] + pb[g].z) * ps[g].z + ph[g].z;
+          float v3 = (acc[i][4 * g + 3] + pb[g].w) * ps[g].w + ph[g].w;
+          v0 += __builtin_bit_cast(float, rr.x << 16); v1 += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+          v2 += __builtin_bit_cast(float, rr.y << 16); v3 += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          *reinterpret_cast<uint2*>(a.out + gp * 32 + 8 * g + 4 * lh) = make_uint2(thin_pack_bf16x2(v0, v1), thin_pack_bf16x2(v2, v3));
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
     __syncthreads();          // every wave is done with sX and sT
