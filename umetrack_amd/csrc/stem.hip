@@ -23,7 +23,7 @@ constexpr int STEM_LDW = 100;                // floats per staged input row: [2 
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __restrict__ images,
                                                    int n, void* __restrict__ out) {
-  __shared__ float sw[9 * 32], sb[32], ss[32], sh[32];
+  __shared__ __attribute__((aligned(8))) float sw[9 * 32], sb[32], ss[32], sh[32];
   __shared__ __attribute__((aligned(16))) float sin_[STEM_IN_ROWS * STEM_LDW];
   const int tid = threadIdx.x;
   for (int i = tid; i < 9 * 32; i += 256) sw[i] = p.w[i];
@@ -63,24 +63,37 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __
 #pragma unroll
       for (int dx = 0; dx < 4; ++dx) patch[dy][dx] = row[dx];
     }
+    // two channels per instruction (v_pk_fma_f32: the packed form is what reaches the vector fp32 rate); each lane of a
+    // pair is the same fmaf chain as before, so the results are unchanged
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     float res[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < 8; c += 2) {
       const int ch = cg * 8 + c;
-      float best = 0.f;  // ReLU output is >= 0, so 0 is the identity of the pooled max
+      f32x2 w2[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) w2[t] = *reinterpret_cast<const f32x2*>(sw + t * 32 + ch);
+      const f32x2 b2 = *reinterpret_cast<const f32x2*>(sb + ch), s2 = *reinterpret_cast<const f32x2*>(ss + ch),
+                  h2 = *reinterpret_cast<const f32x2*>(sh + ch);
+      f32x2 best = {0.f, 0.f};  // ReLU output is >= 0, so 0 is the identity of the pooled max
 #pragma unroll
       for (int py = 0; py < 2; ++py)
 #pragma unroll
         for (int px = 0; px < 2; ++px) {
-          float s = 0.f;
+          f32x2 s = {0.f, 0.f};
 #pragma unroll
           for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) s = fmaf(sw[(ky * 3 + kx) * 32 + ch], patch[py + ky][px + kx], s);
-          const float v = (s + sb[ch]) * ss[ch] + sh[ch];
-          best = fmaxf(best, v);
+            for (int kx = 0; kx < 3; ++kx) {
+              const float pv = patch[py + ky][px + kx];
+              const f32x2 p2 = {pv, pv};
+              s = __builtin_elementwise_fma(w2[ky * 3 + kx], p2, s);
+            }
+          const f32x2 v = (s + b2) * s2 + h2;
+          best = __builtin_elementwise_max(best, v);
         }
-      res[c] = best;
+      res[c] = best.x;
+      res[c + 1] = best.y;
     }
     const size_t pix = ((size_t)img * 48 + yo0 + ry) * 48 + xo;
     if (OUT_BF16) {
