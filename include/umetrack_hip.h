@@ -199,6 +199,19 @@ int64_t umt_metric_workspace_bytes(int n_rec, int t);
 int umt_metric_partials(const float* gt, const float* pred, const uint8_t* valid, int n_rec, int t,
                         double* partials, void* workspace, int64_t workspace_bytes, void* stream);
 
+
+/* ---- umt_metric_partials for callers that cannot allocate.  No counterpart in the reference: it is for
+ * callers that may not call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation) and have no workspace to pass.  Same inputs, outputs and bit-identical results as
+ * umt_metric_partials; the per-workgroup partial sums go to a static device array inside the library
+ * (1.77 MB per GPU, held until the process ends) instead of a workspace.  Limit: n_rec * 2 * t <=
+ * UMT_METRIC_STATIC_MAX_HAND_FRAMES, larger inputs return UMT_ERR_WORKSPACE.  The call allocates nothing
+ * (no hipMalloc / hipFree, no allocating library routine).  All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (different streams or threads) race; serialise them.                    */
+#define UMT_METRIC_STATIC_MAX_HAND_FRAMES 524288
+int umt_metric_partials_static(const float* gt, const float* pred, const uint8_t* valid, int n_rec, int t,
+                               double* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

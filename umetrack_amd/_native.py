@@ -55,7 +55,9 @@ SIGNATURES = {
     "umt_fk_landmarks": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_float, c_int, _P, _P]),
     "umt_metric_workspace_bytes": (c_int64, [c_int, c_int]),
     "umt_metric_partials": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, _P]),
+    "umt_metric_partials_static": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
 }
+METRIC_STATIC_MAX_HAND_FRAMES = 524288
 
 _lib = None
 

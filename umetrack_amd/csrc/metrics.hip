@@ -6,6 +6,8 @@
 // values that RCCL later sums across ranks do not depend on scheduling.
 #include "umt_internal.h"
 
+#include <atomic>
+
 namespace umt {
 
 constexpr int MT = 256;
@@ -92,6 +94,30 @@ __global__ __launch_bounds__(MT) void metric_stage2(const double* __restrict__ p
   }
 }
 
+// ---- allocation-free variant (umt_metric_partials_static): the per-workgroup partials of stage 1 live in a
+// file-scope device array instead of a caller workspace.  Every GPU the library runs on holds its own copy
+// (UMT_METRIC_STATIC_MAX_BLOCKS x 108 doubles = 1.77 MB) until the process ends.  The array's name is only a
+// host-side handle; its device address is resolved once per device with hipGetSymbolAddress and kept here.
+constexpr int STATIC_MAX_BLOCKS = UMT_METRIC_STATIC_MAX_HAND_FRAMES / MT;
+static __device__ __align__(256) double scratch[(size_t)STATIC_MAX_BLOCKS * MW];
+constexpr int MAX_DEVICES = 64;
+static std::atomic<double*> g_scratch_ptr[MAX_DEVICES];   // zero-initialised; a slot only ever goes null -> address
+
+// device address of `scratch` on the current device (resolved on the first call per device; no allocation)
+static int static_scratch(double** out) {
+  int dev = -1;
+  UMT_CHECK_HIP(hipGetDevice(&dev));
+  UMT_REQUIRE(dev >= 0 && dev < MAX_DEVICES, UMT_ERR_UNSUPPORTED, "metrics (static): device index %d >= %d", dev, MAX_DEVICES);
+  double* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    UMT_CHECK_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    UMT_REQUIRE(p != nullptr, UMT_ERR_HIP, "metrics (static): hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[dev].store(p, std::memory_order_release);      // every thread resolves the same address
+  }
+  *out = p;
+  return 0;
+}
+
 }  // namespace umt
 
 extern "C" int64_t umt_metric_workspace_bytes(int n_rec, int t) {
@@ -113,6 +139,27 @@ extern "C" int umt_metric_partials(const float* gt, const float* pred, const uin
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(metric_stage1, dim3(blocks), dim3(MT), 0, s, gt, pred, valid, total, t, (double*)workspace);
   hipLaunchKernelGGL(metric_stage2, dim3(1), dim3(MT), 0, s, (const double*)workspace, blocks, partials);
+  UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int umt_metric_partials_static(const float* gt, const float* pred, const uint8_t* valid, int n_rec, int t,
+                                          double* partials, void* stream) {
+  using namespace umt;
+  UMT_REQUIRE(n_rec > 0 && t > 0, UMT_ERR_INVALID, "metrics (static): n_rec=%d t=%d", n_rec, t);
+  UMT_REQUIRE(gt && pred && valid && partials, UMT_ERR_INVALID, "metrics (static): null pointer");
+  const int64_t total = (int64_t)n_rec * 2 * t;
+  UMT_REQUIRE(total <= (int64_t)UMT_METRIC_STATIC_MAX_HAND_FRAMES, UMT_ERR_WORKSPACE,
+              "metrics (static): %lld hand-frames exceed the static scratch limit of %d; split the call or use "
+              "umt_metric_partials with a workspace", (long long)total, UMT_METRIC_STATIC_MAX_HAND_FRAMES);
+  const int blocks = (int)((total + MT - 1) / MT);
+  double* ws = nullptr;
+  UMT_TRY(static_scratch(&ws));
+  hipStream_t s = (hipStream_t)stream;
+  // stage 1 writes all 108 words of each of its `blocks` rows and stage 2 reads exactly those rows, so what an
+  // earlier (larger) call left in the array is never read: nothing has to be cleared
+  hipLaunchKernelGGL(metric_stage1, dim3(blocks), dim3(MT), 0, s, gt, pred, valid, total, t, ws);
+  hipLaunchKernelGGL(metric_stage2, dim3(1), dim3(MT), 0, s, (const double*)ws, blocks, partials);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
