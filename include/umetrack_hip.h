@@ -48,9 +48,31 @@ enum {
 enum { UMT_PREC_FP32 = 0, UMT_PREC_BF16 = 1, UMT_PREC_FP32_BF16X3 = 2 };
 enum { UMT_HEAD_KNOWN_SKELETON = 0, UMT_HEAD_PREDICT_SCALE = 1 };
 enum { UMT_WARP_CV2_FIXED_POINT = 0, UMT_WARP_FLOAT = 1, UMT_WARP_CV2_FIXED_POINT_F64 = 2 };
+/* OR-ed into `mode`: _warp_image(depth_check=False), tracker.py:59,71-73 - source points behind the camera keep
+ * their projected coordinates instead of mapping to (-1,-1) */
+enum { UMT_WARP_NO_DEPTH_CHECK = 0x100 };
 
 const char* umt_last_error(void);
+/* bumped on every signature change; bindings compare it with the value they were written for */
+#define UMT_ABI_VERSION 2
 int umt_abi_version(void);
+
+/* Conditions a kernel can detect but an asynchronous call cannot return: the kernels OR these bits into a status
+ * word in the model handle and umt_model_status() reads it (one 4-byte copy + stream synchronisation).  Each bit
+ * names what the reference does at that point; the library's behaviour on the device is chosen so that nothing
+ * faults and no state is poisoned. */
+enum {
+  UMT_STATUS_SINGULAR_PREV_EXTRINSICS = 1, /* use_memory on a row whose previous extrinsics are singular (e.g. never
+                                              written): torch.inverse raises (temporal.py:66); here the sample runs as
+                                              use_memory = False */
+  UMT_STATUS_BAD_MEMORY_IDX = 2,           /* memory_idx outside the reserved rows: IndexError in the reference; here the
+                                              sample runs without memory and writes none */
+  UMT_STATUS_BAD_SAMPLE_RANGE = 4,         /* sample_range row outside [0, n] or not 1 or 2 views: the sample's outputs
+                                              are NaN */
+  UMT_STATUS_NONFINITE_OUTPUT = 8,         /* a regressor output row was not finite: its decoded outputs are NaN */
+  UMT_STATUS_BAD_BONE_INDEX = 16           /* umt_fk_landmarks: a landmark's bone index outside [0, 16] (IndexError in
+                                              the reference); that landmark is NaN */
+};
 
 /* ---- model handle: replaces load_pretrained_model, lib/models/model_loader.py:53-88 ---- */
 int umt_model_create(umt_model** out);
@@ -70,6 +92,8 @@ int umt_model_memory_rows(const umt_model* m, int* rows);
 int umt_model_clear_memory(umt_model* m);                              /* back to 0 rows */
 /* copy state out for inspection: mem (rows,18,6,6), prev_ext (rows,4,4), both dev */
 int umt_model_read_memory(const umt_model* m, float* mem_dev, float* prev_ext_dev, void* stream);
+/* copies the UMT_STATUS_* word to *status_host (host memory), optionally clears it, and waits for `stream` */
+int umt_model_status(umt_model* m, int32_t* status_host, int clear, void* stream);
 
 /* ---- workspace sizes (bytes) ---- */
 int64_t umt_backbone_workspace_bytes(int n_crops);
@@ -133,7 +157,10 @@ int umt_fuse_views(umt_model* m, const float* features, const float* intrinsics,
 /* ---- A8: SimpleConvRNN.forward_temporal_features, lib/models/temporal.py:93-139 ----
  * cam0_extrinsics dev f32 (bs,4,4) = extrinsics[sample_range[:,0]] (umetrack_model.py:93-97);
  * memory_idx dev int64 (bs), use_memory dev uint8/bool (bs).  The caller must have reserved
- * max(memory_idx)+1 rows.  out dev f32 (bs,72,6,6); updates the handle's state.                     */
+ * max(memory_idx)+1 rows.  out dev f32 (bs,72,6,6); updates the handle's state.
+ * All previous state is read before any is written (as temporal.py:66-77).  Duplicate memory_idx values in one
+ * batch all read the same previous row; the sample with the highest batch index writes it (last wins, as torch's
+ * CPU index assignment).  See UMT_STATUS_SINGULAR_PREV_EXTRINSICS / UMT_STATUS_BAD_MEMORY_IDX.                 */
 int umt_temporal_step(umt_model* m, const float* fused, const float* cam0_extrinsics,
                       const int64_t* memory_idx, const uint8_t* use_memory, int bs, float* out,
                       void* workspace, int64_t workspace_bytes, void* stream);
@@ -183,11 +210,13 @@ int umt_model_layer_timing_read(umt_model* m, int max_layers, char* names, doubl
  * joint_angles dev f32 (b,22); wrist dev f32 (b,4,4); hand model arrays dev with n_model in {1,b}:
  * axes,rest f32 (n_model,22,3); lm_rest f32 (n_model,21,3); lm_w f32 (n_model,21,3);
  * lm_idx int32 (n_model,21,3); hand_idx dev int64 (b) or NULL; wrist_t_scale multiplies the wrist
- * translation (1000 for the m->mm step of tracker.py:258); out dev f32 (b,21,3)                     */
+ * translation (1000 for the m->mm step of tracker.py:258); out dev f32 (b,21,3);
+ * status dev int32[1] or NULL: UMT_STATUS_BAD_BONE_INDEX is OR-ed in when a used bone index (weight != 0) is
+ * outside [0, 16] - the reference raises IndexError there; the landmark is written as NaN                      */
 int umt_fk_landmarks(const float* joint_angles, const float* wrist, const float* axes,
                      const float* rest, const float* lm_rest, const float* lm_w,
                      const int32_t* lm_idx, int n_model, const int64_t* hand_idx, int mirror_right,
-                     float wrist_t_scale, int b, float* out, void* stream);
+                     float wrist_t_scale, int b, float* out, int32_t* status, void* stream);
 
 /* ---- A15: _compute_metrics + the sums behind aggregate_metrics, load_eval.py:26-89,
  * metric_utils.py:18-84.  gt/pred dev f32 (n_rec,2,T,21,3), valid dev uint8 (n_rec,2,T).

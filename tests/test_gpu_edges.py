@@ -91,7 +91,7 @@ def test_error_codes_instead_of_faults(pair):
     fused = gm.fuse_views(feats, K, E, torch.tensor([[0, 2], [2, 9]]))
     assert torch.isfinite(fused[0]).all() and torch.isnan(fused[1]).all()
     # empty batches are no-ops for the pointwise entry points
-    assert L.umt_fk_landmarks(None, None, None, None, None, None, None, 1, None, 0, ctypes.c_float(1.0), 0, None, st) == 0
+    assert L.umt_fk_landmarks(None, None, None, None, None, None, None, 1, None, 0, ctypes.c_float(1.0), 0, None, None, st) == 0
     assert L.umt_warp_crops(None, None, None, None, None, 0, 96, 96, 0, None, st) == 0
 
 

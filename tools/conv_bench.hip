@@ -28,6 +28,7 @@ int main(int argc, char** argv) {
                           {32, 64, 48, 9, 2, 0}, {64, 128, 24, 9, 2, 0}, {128, 256, 12, 9, 2, 0}, {32, 64, 48, 1, 2, 0},
                           {128, 256, 12, 1, 2, 0}};
   const int only = argc > 3 ? atoi(argv[3]) : -1;      // index into shapes[], -1 = all
+  if (conv_prepare_device() != 0) return 1;            // dynamic-LDS limits (the library does this at umt_model_finalize)
 
 
   // fused stride-2 conv1 + down-sample: split-operand kernel vs the fp32 fused kernel
@@ -209,17 +210,17 @@ int main(int argc, char** argv) {
         if (bf) launch_conv_bf16(L, (const uint16_t*)in, n, sh.hw, sh.hw, sh.res ? (const uint16_t*)res : nullptr, out, 0, 0);
         else launch_conv(L, (const float*)in, n, sh.hw, sh.hw, sh.res ? (const float*)res : nullptr, (float*)out, 0);
       };
-      if ((bf && (conv_thin_applicable(L, sh.hw) || g_conv_thin == 0)) ||
+      if ((bf && (conv_thin_applicable(L, sh.hw) || (L.flags & CONV_NO_THIN))) ||
           (!bf && sh.cin == 32 && sh.cout == 32 && sh.taps == 9 && sh.stride == 1)) {   // new kernel vs the one-tile-per-workgroup kernel
         ConvLayer L2 = L;
         std::vector<unsigned char> r0(out_n * esz), r1(out_n * esz);
-        g_conv_thin = 0; run(); hipDeviceSynchronize(); hipMemcpy(r0.data(), out, out_n * esz, hipMemcpyDeviceToHost);
+        L.flags |= CONV_NO_THIN; run(); hipDeviceSynchronize(); hipMemcpy(r0.data(), out, out_n * esz, hipMemcpyDeviceToHost);
         hipMemset(out, 0xff, out_n * esz);
-        g_conv_thin = 1; run(); hipDeviceSynchronize(); hipMemcpy(r1.data(), out, out_n * esz, hipMemcpyDeviceToHost);
+        L.flags &= ~CONV_NO_THIN; run(); hipDeviceSynchronize(); hipMemcpy(r1.data(), out, out_n * esz, hipMemcpyDeviceToHost);
         size_t bad = 0;
         for (size_t i = 0; i < out_n * esz; ++i) bad += r0[i] != r1[i];
         printf("  thin vs halo: %zu differing bytes of %zu\n", bad, out_n * esz);
-        if (getenv("THIN_OFF")) g_conv_thin = 0;
+        if (getenv("THIN_OFF")) L.flags |= CONV_NO_THIN;
       }
       hipEvent_t e0, e1;
       hipEventCreate(&e0); hipEventCreate(&e1);

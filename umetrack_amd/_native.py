@@ -15,7 +15,15 @@ LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
 PREC_FP32, PREC_BF16, PREC_FP32_BF16X3 = 0, 1, 2
 HEAD_KNOWN_SKELETON, HEAD_PREDICT_SCALE = 0, 1
 WARP_CV2_FIXED_POINT, WARP_FLOAT, WARP_CV2_FIXED_POINT_F64 = 0, 1, 2
+WARP_NO_DEPTH_CHECK = 0x100
 METRIC_WORDS = 108
+ABI_VERSION = 2          # UMT_ABI_VERSION of include/umetrack_hip.h these signatures were written for
+STATUS_BITS = {1: "use_memory on a memory row whose previous extrinsics are singular (torch.inverse raises in the "
+                  "reference, temporal.py:66); the sample ran as use_memory=False",
+               2: "memory_idx outside the reserved memory rows",
+               4: "sample_range row outside [0, n] or not 1 or 2 views",
+               8: "a regressor output row was not finite (NaN/inf in the crop, the weights or the state)",
+               16: "a landmark bone index outside [0, 16]"}
 
 _ERR_NAMES = {1: "invalid argument", 2: "bad state", 3: "state_dict key", 4: "HIP runtime",
               5: "workspace", 6: "unsupported"}
@@ -35,6 +43,7 @@ SIGNATURES = {
     "umt_model_memory_rows": (c_int, [_P, POINTER(c_int)]),
     "umt_model_clear_memory": (c_int, [_P]),
     "umt_model_read_memory": (c_int, [_P, _P, _P, _P]),
+    "umt_model_status": (c_int, [_P, POINTER(c_int32), c_int, _P]),
     "umt_backbone_workspace_bytes": (c_int64, [c_int]),
     "umt_head_workspace_bytes": (c_int64, [c_int, c_int]),
     "umt_forward_workspace_bytes": (c_int64, [c_int, c_int]),
@@ -52,7 +61,7 @@ SIGNATURES = {
     "umt_model_timing_read": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
     "umt_model_layer_timing_enable": (c_int, [_P, c_int]),
     "umt_model_layer_timing_read": (c_int, [_P, c_int, _P, POINTER(c_double), POINTER(c_double), POINTER(c_int), POINTER(c_int)]),
-    "umt_fk_landmarks": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_float, c_int, _P, _P]),
+    "umt_fk_landmarks": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_float, c_int, _P, _P, _P]),
     "umt_metric_workspace_bytes": (c_int64, [c_int, c_int]),
     "umt_metric_partials": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, c_int64, _P]),
     "umt_metric_partials_static": (c_int, [_P, _P, _P, c_int, c_int, _P, _P]),
@@ -77,6 +86,10 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)        # AttributeError here = header and library disagree
             fn.restype, fn.argtypes = res, args
+        got = handle.umt_abi_version()
+        if got != ABI_VERSION:                # a stale .so would be called with mismatched signatures
+            raise UmtError(f"{LIB_PATH} reports ABI version {got}, this binding is written for {ABI_VERSION}: "
+                           "rebuild it with `make -C umetrack_amd/csrc`")
         _lib = handle
     return _lib
 

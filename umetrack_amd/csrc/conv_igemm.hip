@@ -524,7 +524,7 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   a.M = (int)M;
   a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
-  static const bool force_gather = getenv("UMT_CONV_GATHER") != nullptr;   // A/B switch for profiling
+  const bool force_gather = (L.flags & CONV_GATHER) != 0;
   if (L.taps == 9 && L.stride == 1 && w <= 48 && !force_gather) {
     if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
     else if (L.cout_w == 96) launch_halo<UMT_CFG96>(a, stream);
@@ -543,20 +543,31 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   return 0;
 }
 
-static unsigned char g_s2_lds_done[2][64];
 int conv_thin_prepare_device();
+int conv_x3_prepare_device();
+
+unsigned conv_flags_from_env() {
+  static const struct { const char* name; unsigned bit; } kSwitches[] = {
+      {"UMT_CONV_NOTHIN", CONV_NO_THIN},         {"UMT_CONV_NOFUSE", CONV_NO_FUSE}, {"UMT_CONV_NOSTREAM128", CONV_NO_STREAM128},
+      {"UMT_CONV_NOTHIN_F32", CONV_NO_THIN_F32}, {"UMT_CONV_GATHER", CONV_GATHER},  {"UMT_CONV_NOS2", CONV_NO_S2},
+      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}};
+  unsigned f = 0;
+  for (const auto& s : kSwitches)
+    if (getenv(s.name)) f |= s.bit;
+  return f;
+}
 
 int conv_prepare_device() {
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, false>), lds, g_s2_lds_done[0]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, true>), lds, g_s2_lds_done[1]));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, false>), lds));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, true>), lds));
+  UMT_TRY(conv_x3_prepare_device());
   return conv_thin_prepare_device();
 }
 
 // conv1 (3x3, stride 2) of a stage's first block, fused with its down-sample 1x1 (ds may be null).
 bool conv_s2_fused_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w) {
-  static const bool off = getenv("UMT_CONV_NOS2") != nullptr;     // A/B switch for profiling
-  if (off || c1.taps != 9 || c1.stride != 2 || (h & 1) || (w & 1) || c1.cout_w % 64 != 0 || c1.cin_s % 8 != 0) return false;
+  if ((c1.flags & CONV_NO_S2) || c1.taps != 9 || c1.stride != 2 || (h & 1) || (w & 1) || c1.cout_w % 64 != 0 || c1.cin_s % 8 != 0) return false;
   const int wo = w / 2;
   if (2 * w * ((S2_BM - 1 + wo - 1) / wo) + 3 * w + 1 > S2_ROWS_MAX) return false;
   if (ds && (ds->taps != 1 || ds->stride != 2 || ds->cin_s != c1.cin_s || ds->cout_w != c1.cout_w || ds->cout_s != c1.cout_s))
@@ -585,7 +596,6 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
   // weight double buffers of both convolutions for two tiles and spill
   dim3 grid((a.M + S2_BM - 1) / S2_BM, c1.cout_w / 64);
   void (*kern)(ConvS2Args) = ds ? conv3x3s2_ds_f32<1, true> : conv3x3s2_ds_f32<1, false>;
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, ds ? g_s2_lds_done[1] : g_s2_lds_done[0]));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;

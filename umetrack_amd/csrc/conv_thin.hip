@@ -25,6 +25,11 @@
 
 namespace umt {
 
+// max(v, 0) as one integer max on the bits, as conv_f32_common.h: negative floats are negative integers, -0 -> +0,
+// and a (positive, canonical) NaN stays a NaN, so a poisoned activation is not laundered into a finite one
+__device__ __forceinline__ float thin_relu(float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), 0)); }
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -233,8 +238,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
               u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
             }
             if (a.relu) {
-              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-              u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+              v.x = thin_relu(v.x); v.y = thin_relu(v.y); v.z = thin_relu(v.z); v.w = thin_relu(v.w);
+              u.x = thin_relu(u.x); u.y = thin_relu(u.y); u.z = thin_relu(u.z); u.w = thin_relu(u.w);
             }
             if (m < a.M)
               *reinterpret_cast<uint4*>(out + (size_t)m * 32 + 8 * q) =
@@ -407,8 +412,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
               u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
             }
             if (a.relu) {
-              v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-              u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+              v.x = thin_relu(v.x); v.y = thin_relu(v.y); v.z = thin_relu(v.z); v.w = thin_relu(v.w);
+              u.x = thin_relu(u.x); u.y = thin_relu(u.y); u.z = thin_relu(u.z); u.w = thin_relu(u.w);
             }
             if (m < a.M)
               *reinterpret_cast<uint4*>(out + (size_t)m * 64 + co) =
@@ -604,8 +609,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
                 u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
               }
               if (a.relu) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f);
+                v.x = thin_relu(v.x); v.y = thin_relu(v.y); v.z = thin_relu(v.z); v.w = thin_relu(v.w);
+                u.x = thin_relu(u.x); u.y = thin_relu(u.y); u.z = thin_relu(u.z); u.w = thin_relu(u.w);
               }
               if (m < a.M)
                 *reinterpret_cast<uint4*>(out + (size_t)m * 128 + co) =
@@ -928,7 +933,7 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
           float v1 = (acc[i][4 * g + 1] + pb[g].y) * ps[g].y + ph[g].y;
           float v2 = (acc[i][4 * g + 2] + pb[g].z) * ps[g].z + ph[g].z;
           float v3 = (acc[i][4 * g + 3] + pb[g].w) * ps[g].w + ph[g].w;
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          v0 = thin_relu(v0); v1 = thin_relu(v1); v2 = thin_relu(v2); v3 = thin_relu(v3);
           uint2 o = make_uint2(thin_pack_bf16x2(v0, v1), thin_pack_bf16x2(v2, v3));
           if (pad) o = make_uint2(0, 0);
           *reinterpret_cast<uint2*>(sT + (ff * T_LDH + 8 * g + 4 * lh) * 2) = o;
@@ -999,7 +1004,7 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
           float v3 = (acc[i][4 * g + 3] + pb[g].w) * ps[g].w + ph[g].w;
           v0 += __builtin_bit_cast(float, rr.x << 16); v1 += __builtin_bit_cast(float, rr.x & 0xffff0000u);
           v2 += __builtin_bit_cast(float, rr.y << 16); v3 += __builtin_bit_cast(float, rr.y & 0xffff0000u);
-          v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f);
+          v0 = thin_relu(v0); v1 = thin_relu(v1); v2 = thin_relu(v2); v3 = thin_relu(v3);
           *reinterpret_cast<uint2*>(a.out + gp * 32 + 8 * g + 4 * lh) = make_uint2(thin_pack_bf16x2(v0, v1), thin_pack_bf16x2(v2, v3));
         }
       }
@@ -1011,32 +1016,20 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------- launch
-static int cu_count() {
-  static int cached[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!cached[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev] = n;
-  }
-  return cached[dev];
-}
-
-int g_conv_thin = -1;      // -1: decide from the environment once; 0 / 1: forced (tools/conv_bench.hip)
+// gfx950 only (umt_model_finalize checks the architecture): an MI355X has 256 CUs; a partition mode with fewer
+// only means some persistent workgroups queue behind others.
+static int cu_count() { return 256; }
 
 static bool thin64_shape(const ConvLayer& L, int w) {
   return L.taps == 9 && L.stride == 1 && L.cin_s == 64 && L.cout_s == 64 && L.cout_w == 64 && w <= W64_WMAX;
 }
 
 static bool stream128_shape(const ConvLayer& L, int w) {
-  static const int off = getenv("UMT_CONV_NOSTREAM128") ? 1 : 0;
-  return !off && L.taps == 9 && L.stride == 1 && L.cin_s == 128 && L.cout_s == 128 && L.cout_w == 128 && w <= S128_WMAX;
+  return !(L.flags & CONV_NO_STREAM128) && L.taps == 9 && L.stride == 1 && L.cin_s == 128 && L.cout_s == 128 && L.cout_w == 128 && w <= S128_WMAX;
 }
 
 bool conv_thin_applicable(const ConvLayer& L, int w) {
-  if (g_conv_thin < 0) g_conv_thin = getenv("UMT_CONV_NOTHIN") ? 0 : 1;     // A/B switch for profiling
-  if (!g_conv_thin || L.taps != 9 || L.stride != 1) return false;
+  if ((L.flags & CONV_NO_THIN) || L.taps != 9 || L.stride != 1) return false;
   return (L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48) || thin64_shape(L, w) || stream128_shape(L, w);
 }
 
@@ -1051,11 +1044,9 @@ static int grid_for(int ntiles, int per_cu) {
 #define UMT_THIN_TM 2
 #endif
 
-static unsigned char g_thin_lds_done[2][64];
 static size_t thin_lds_bytes(int tm, int w) {
   return 2 * ((((size_t)(128 * tm + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
-static unsigned char g_w64_lds_done[2][64];
 static size_t w64_lds_bytes(int w) {
   return (size_t)W64_WBYTES + W64_CBYTES +
          2 * ((((size_t)(W64_BM + 2 * w + 2 + 1) * W64_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
@@ -1064,19 +1055,16 @@ static_assert((size_t)W64_WBYTES + W64_CBYTES + 2 * ((((size_t)(W64_BM + 2 * W64
                                                        4 * 32 * T_LDP * sizeof(float)) <= 160 * 1024,
               "conv3x3_wlds64_bf16: LDS budget");
 
-static unsigned char g_s128_lds_done[2][64];
 static size_t s128_lds_bytes(int w) {
   return (size_t)S128_CBYTES + 2 * ((((size_t)(S128_BM + 2 * w + 2 + 1) * S128_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
 
-static unsigned char g_fb_lds_done[64];
 bool block32_fused_applicable(const ConvLayer& c1, const ConvLayer& c2, int h, int w) {
-  static const int off = getenv("UMT_CONV_NOFUSE") ? 1 : 0;      // A/B switch for profiling and the bit-identity test
-  if (g_conv_thin < 0) g_conv_thin = getenv("UMT_CONV_NOTHIN") ? 0 : 1;
+  const bool off = (c1.flags & (CONV_NO_FUSE | CONV_NO_THIN)) != 0;
   auto ok = [](const ConvLayer& L) {
     return L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && L.wh != nullptr;
   };
-  return !off && g_conv_thin && h == FB_H && w == FB_W && ok(c1) && ok(c2) && c1.relu && c2.relu;
+  return !off && h == FB_H && w == FB_W && ok(c1) && ok(c2) && c1.relu && c2.relu;
 }
 
 int launch_block32_fused_bf16(const ConvLayer& c1, const ConvLayer& c2, const uint16_t* in, int n, uint16_t* out,
@@ -1087,13 +1075,11 @@ int launch_block32_fused_bf16(const ConvLayer& c1, const ConvLayer& c2, const ui
   a.bias1 = c1.bias; a.scale1 = c1.scale; a.shift1 = c1.shift;
   a.bias2 = c2.bias; a.scale2 = c2.scale; a.shift2 = c2.shift;
   a.ntiles = n * (FB_H / FB_R);
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(block32_fused_bf16), FB_LDS, g_fb_lds_done));
   hipLaunchKernelGGL(block32_fused_bf16, dim3(grid_for(a.ntiles, 1)), dim3(512), FB_LDS, stream, a);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
-static unsigned char g_f32_lds_done[2][64];
 static size_t f32_lds_bytes(int w) {
   return (size_t)F32_WBYTES + 2 * ((size_t)(F32_BM + 2 * w + 2 + 1) * F32_LDA * 4 + 4 * 32 * F32_LDA * sizeof(float));
 }
@@ -1101,8 +1087,7 @@ static_assert((size_t)F32_WBYTES + 2 * ((size_t)(F32_BM + 2 * 48 + 2 + 1) * F32_
               "conv3x3_wlds32_f32: LDS budget");
 
 bool conv_thin_f32_applicable(const ConvLayer& L, int w) {
-  static const int off = getenv("UMT_CONV_NOTHIN_F32") ? 1 : 0;     // A/B switch for profiling and the bit-identity test
-  return !off && g_conv_thin != 0 && L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48;
+  return !(L.flags & (CONV_NO_THIN_F32 | CONV_NO_THIN)) && L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48;
 }
 
 int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual, float* out,
@@ -1117,22 +1102,21 @@ int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int 
   a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
   auto kern = residual ? conv3x3_wlds32_f32<true> : conv3x3_wlds32_f32<false>;
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), f32_lds_bytes(48), residual ? g_f32_lds_done[1] : g_f32_lds_done[0]));
   hipLaunchKernelGGL(kern, dim3(grid_for(a.ntiles, 1)), dim3(512), f32_lds_bytes(w), stream, a);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
 int conv_thin_prepare_device() {      // largest request: W = 48
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(block32_fused_bf16), FB_LDS, g_fb_lds_done));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<false>), f32_lds_bytes(48), g_f32_lds_done[0]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<true>), f32_lds_bytes(48), g_f32_lds_done[1]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<false>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[0]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<true>), s128_lds_bytes(S128_WMAX), g_s128_lds_done[1]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[0]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<true>), w64_lds_bytes(W64_WMAX), g_w64_lds_done[1]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, false>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[0]));
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, true>), thin_lds_bytes(UMT_THIN_TM, 48), g_thin_lds_done[1]));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(block32_fused_bf16), FB_LDS));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<false>), f32_lds_bytes(48)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<true>), f32_lds_bytes(48)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<false>), s128_lds_bytes(S128_WMAX)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<true>), s128_lds_bytes(S128_WMAX)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<true>), w64_lds_bytes(W64_WMAX)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, false>), thin_lds_bytes(UMT_THIN_TM, 48)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, true>), thin_lds_bytes(UMT_THIN_TM, 48)));
   return 0;
 }
 
@@ -1150,7 +1134,6 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
     a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
     a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
     auto kern128 = residual ? conv3x3_stream128_bf16<true> : conv3x3_stream128_bf16<false>;
-    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern128), s128_lds_bytes(S128_WMAX), residual ? g_s128_lds_done[1] : g_s128_lds_done[0]));
     hipLaunchKernelGGL(kern128, dim3(grid_for(a.ntiles, 1)), dim3(512), s128_lds_bytes(w), stream, a);
     UMT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1160,7 +1143,6 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
     a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
     a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
     auto kern64 = residual ? conv3x3_wlds64_bf16<true> : conv3x3_wlds64_bf16<false>;
-    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern64), w64_lds_bytes(W64_WMAX), residual ? g_w64_lds_done[1] : g_w64_lds_done[0]));
     hipLaunchKernelGGL(kern64, dim3(grid_for(a.ntiles, 1)), dim3(512), w64_lds_bytes(w), stream, a);
     UMT_CHECK_HIP(hipGetLastError());
     return 0;
@@ -1171,7 +1153,6 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
   const size_t lds = thin_lds_bytes(TM, w);
   const dim3 grid(grid_for(a.ntiles, 1));
   auto kern = residual ? conv3x3_thin32_bf16<TM, true> : conv3x3_thin32_bf16<TM, false>;
-  UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), thin_lds_bytes(TM, 48), residual ? g_thin_lds_done[1] : g_thin_lds_done[0]));
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, a);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;

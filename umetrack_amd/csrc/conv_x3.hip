@@ -214,11 +214,7 @@ static void launch_halo_x3(const ConvArgs& a, hipStream_t stream) {
   if (lds < patch) lds = patch;
   void (*kern)(ConvArgs) = a.residual ? conv3x3s1_halo_x3<WAVES_M, WAVES_N, TM, TN, true>
                                       : conv3x3s1_halo_x3<WAVES_M, WAVES_N, TM, TN, false>;
-  if (lds > 65536) {
-    static unsigned char done[2][64];
-    if (ensure_dynamic_lds(reinterpret_cast<const void*>(kern), 160 * 1024 - 256, done[a.residual ? 1 : 0])) return;
-  }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a);      // > 64 KB of LDS: see conv_x3_prepare_device
 }
 
 // ------------------------------------------------------------------------------ stride 2 + down-sample
@@ -385,8 +381,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_x3(ConvS2ArgsX3 g) {
 }
 
 bool conv_s2_x3_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w) {
-  static const bool off = getenv("UMT_X3_NOS2") != nullptr;     // A/B switch for profiling
-  if (off || !c1.wx3 || (ds && !ds->wx3) || c1.cin_s % 16 != 0 || c1.cout_w % 128 != 0) return false;   // see below for 64
+  if ((c1.flags & CONV_X3_NO_S2) || !c1.wx3 || (ds && !ds->wx3) || c1.cin_s % 16 != 0 || c1.cout_w % 128 != 0) return false;   // see below for 64
   return conv_s2_fused_applicable(c1, ds, h, w);
 }
 
@@ -414,10 +409,6 @@ int launch_conv_s2_fused_x3(const ConvLayer& c1, const ConvLayer* ds, const floa
   // 433 staged rows need 90 KB of LDS, one workgroup per CU, 1.17 ms against 1.09 ms for conv3x3s2_ds_f32.
   dim3 grid((a.M + X3S2_BM - 1) / X3S2_BM, c1.cout_w / 128);
   void (*kern)(ConvS2ArgsX3) = ds ? conv3x3s2_ds_x3<1, 2, true> : conv3x3s2_ds_x3<1, 2, false>;
-  if (lds > 65536) {
-    static unsigned char done[2][64];
-    UMT_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, done[ds ? 1 : 0]));
-  }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
@@ -448,6 +439,22 @@ int launch_conv_x3(const ConvLayer& L, const float* in, int n, int h, int w, con
   else if (L.cout_w == 64) launch_halo_x3<UMT_X3_CFG64>(a, stream);
   else launch_halo_x3<UMT_X3_CFG32>(a, stream);
   UMT_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// every instance that can ask for more than 64 KB of dynamic LDS (called by conv_prepare_device at umt_model_finalize)
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+static int prepare_halo_x3() {
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s1_halo_x3<WAVES_M, WAVES_N, TM, TN, true>), 160 * 1024 - 256));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s1_halo_x3<WAVES_M, WAVES_N, TM, TN, false>), 160 * 1024 - 256));
+  return 0;
+}
+int conv_x3_prepare_device() {
+  UMT_TRY((prepare_halo_x3<2, 2, 2, 2>()));
+  UMT_TRY((prepare_halo_x3<UMT_X3_CFG64>()));
+  UMT_TRY((prepare_halo_x3<UMT_X3_CFG32>()));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_x3<1, 2, true>), 160 * 1024 - 256));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_x3<1, 2, false>), 160 * 1024 - 256));
   return 0;
 }
 

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(64 * FK_WAVES) void fk_kernel(
     const float* __restrict__ joint_angles, const float* __restrict__ wrist, const float* __restrict__ axes,
     const float* __restrict__ rest, const float* __restrict__ lm_rest, const float* __restrict__ lm_w,
     const int32_t* __restrict__ lm_idx, int n_model, const int64_t* __restrict__ hand_idx, int mirror_right,
-    float t_scale, int b_total, float* __restrict__ out) {
+    float t_scale, int b_total, float* __restrict__ out, int32_t* __restrict__ status) {
   __shared__ float sL[FK_WAVES][20][12];
   __shared__ float sF[FK_WAVES][17][12];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -96,9 +96,15 @@ __global__ __launch_bounds__(64 * FK_WAVES) void fk_kernel(
     const float px = lm_rest[mo], py = lm_rest[mo + 1], pz = lm_rest[mo + 2];
     int idx[3];
     float wt[3];
+    // A used bone index (weight != 0) outside [0, 16]: the reference scatters the weight through a flattened index
+    // (hand_skinning.py:87-94), so it lands in a neighbouring landmark's row or raises IndexError.  Here the landmark
+    // becomes NaN and UMT_STATUS_BAD_BONE_INDEX is reported; the clamp below only keeps the LDS access in range.
+    bool bad_index = false;
     for (int k = 0; k < 3; ++k) {
-      idx[k] = min(max(lm_idx[mo + k], 0), 16);
+      const int raw_idx = lm_idx[mo + k];
       wt[k] = lm_w[mo + k];
+      bad_index = bad_index || (wt[k] != 0.f && (raw_idx < 0 || raw_idx > 16));
+      idx[k] = min(max(raw_idx, 0), 16);
     }
     // dense weights are written by assignment: a later non-zero entry for the same bone wins
     if (wt[0] != 0.f && ((wt[1] != 0.f && idx[1] == idx[0]) || (wt[2] != 0.f && idx[2] == idx[0]))) wt[0] = 0.f;
@@ -112,6 +118,10 @@ __global__ __launch_bounds__(64 * FK_WAVES) void fk_kernel(
       oy += M[4] * qx + M[5] * qy + M[6] * qz + M[7] * qw;
       oz += M[8] * qx + M[9] * qy + M[10] * qz + M[11] * qw;
     }
+    if (bad_index) {
+      ox = oy = oz = __builtin_nanf("");
+      if (status) atomicOr(status, UMT_STATUS_BAD_BONE_INDEX);
+    }
     float* o = out + ((size_t)b * 21 + lane) * 3;
     o[0] = ox; o[1] = oy; o[2] = oz;
   }
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(64 * FK_WAVES) void fk_kernel(
 extern "C" int umt_fk_landmarks(const float* joint_angles, const float* wrist, const float* axes, const float* rest,
                                 const float* lm_rest, const float* lm_w, const int32_t* lm_idx, int n_model,
                                 const int64_t* hand_idx, int mirror_right, float wrist_t_scale, int b, float* out,
-                                void* stream) {
+                                int32_t* status, void* stream) {
   using namespace umt;
   if (b == 0) return 0;
   UMT_REQUIRE(b > 0, UMT_ERR_INVALID, "fk: b = %d", b);
@@ -132,7 +142,7 @@ extern "C" int umt_fk_landmarks(const float* joint_angles, const float* wrist, c
   UMT_REQUIRE(!mirror_right || hand_idx, UMT_ERR_INVALID, "fk: mirror_right needs hand_idx");
   const unsigned blocks = (unsigned)((b + FK_WAVES - 1) / FK_WAVES);
   hipLaunchKernelGGL(fk_kernel, dim3(blocks), dim3(64 * FK_WAVES), 0, (hipStream_t)stream, joint_angles, wrist, axes,
-                     rest, lm_rest, lm_w, lm_idx, n_model, hand_idx, mirror_right, wrist_t_scale, b, out);
+                     rest, lm_rest, lm_w, lm_idx, n_model, hand_idx, mirror_right, wrist_t_scale, b, out, status);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -23,8 +23,10 @@ __device__ inline void mat4_mul(const double* a, const double* b, double* c) {
     }
 }
 
-// Gauss-Jordan with partial pivoting; a singular input yields inf/nan like torch.inverse would raise.
-__device__ inline void mat4_inv(const double* m, double* inv) {
+// Gauss-Jordan with partial pivoting; a singular input yields inf/nan where torch.inverse would raise.
+// Returns false when a pivot is exactly zero or not finite (the matrix is singular to working precision).
+__device__ inline bool mat4_inv(const double* m, double* inv) {
+  bool regular = true;
   double a[4][8];
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) {
@@ -38,6 +40,7 @@ __device__ inline void mat4_inv(const double* m, double* inv) {
       if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
     if (piv != col)
       for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+    if (!(fabs(a[col][col]) > 0.0) || !isfinite(a[col][col])) regular = false;
     const double d = 1.0 / a[col][col];
     for (int j = 0; j < 8; ++j) a[col][j] *= d;
     for (int r = 0; r < 4; ++r)
@@ -48,6 +51,7 @@ __device__ inline void mat4_inv(const double* m, double* inv) {
   }
   for (int i = 0; i < 4; ++i)
     for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
+  return regular;
 }
 
 __device__ inline void load_mat4(const float* src, double* dst) {
@@ -121,7 +125,7 @@ int launch_gather_cam0(const float* extrinsics, const int64_t* sample_range, int
 // sample_xf[bs][12]: canonical -> cam0 (= S of the sample's first crop).  sample_views[bs]: 1 or 2
 // (0 marks a malformed range; its outputs become NaN instead of reading out of bounds).
 __global__ void fusion_xforms_kernel(const float* K, const float* E, const int64_t* sr, int n, int bs,
-                                     float* crop_xf, float* sample_xf, int32_t* sample_views) {
+                                     float* crop_xf, float* sample_xf, int32_t* sample_views, int32_t* status) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= bs) return;
   const int64_t r0 = sr[2 * b], r1 = sr[2 * b + 1];
@@ -129,6 +133,7 @@ __global__ void fusion_xforms_kernel(const float* K, const float* E, const int64
   const bool okr = r0 >= 0 && r1 <= n && (nv == 1 || nv == 2);
   sample_views[b] = okr ? nv : 0;
   if (!okr) {
+    if (status) atomicOr(status, UMT_STATUS_BAD_SAMPLE_RANGE);
     for (int i = 0; i < 12; ++i) sample_xf[b * 12 + i] = __builtin_nanf("");
     return;
   }
@@ -158,9 +163,10 @@ __global__ void fusion_xforms_kernel(const float* K, const float* E, const int64
 }
 
 int launch_fusion_xforms(const float* intrinsics, const float* extrinsics, const int64_t* sample_range,
-                         int n, int bs, float* crop_xf, float* sample_xf, int32_t* sample_views, hipStream_t s) {
+                         int n, int bs, float* crop_xf, float* sample_xf, int32_t* sample_views, int32_t* status,
+                         hipStream_t s) {
   hipLaunchKernelGGL(fusion_xforms_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, intrinsics, extrinsics,
-                     sample_range, n, bs, crop_xf, sample_xf, sample_views);
+                     sample_range, n, bs, crop_xf, sample_xf, sample_views, status);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -231,10 +237,22 @@ int launch_ftl_select(const float* conv_rows, const float* feat_rows, const floa
 }
 
 // ---------------------------------------------------------------- temporal memory (A8)
-// One thread per sample: relative transform cur_E . inverse(prev_E[idx]) (temporal.py:65-69),
-// then prev_E[idx] = cur_E (temporal.py:77).  rel_xf[b][12]; rows without memory get NaN-free zeros.
-__global__ void temporal_xforms_kernel(float* prev_ext, int mem_rows, const float* cam0, const int64_t* midx,
-                                       const uint8_t* use, int bs, float* rel_xf, int32_t* row_of) {
+// The temporal step reads ALL previous state before it writes any (temporal.py:66-77 builds every relative
+// transform from prev_extrinsics and only then assigns prev_extrinsics[memory_idx] = cur).  Three launches in stream
+// order give the same ordering on the device:
+//   1. temporal_xforms_kernel   reads prev_E[idx], writes rel_xf[b], claims row idx for sample b
+//   2. temporal_gather_kernel   reads mem[idx] (and, in the same launch, the winners write prev_E[idx] = cur_E)
+//   3. temporal_split_kernel    (after the three convolutions) winners write mem[idx]
+// Duplicate memory_idx values in one batch: every duplicate READS the same previous state; the sample with the
+// HIGHEST batch index writes the row (torch's CPU index assignment is last-wins too).  The claim is an atomicMax of
+// (epoch << 32 | b) into mem_owner[idx], epoch = one per step, so no claim array has to be cleared.
+// row_of[b]: memory row of sample b, or -1 (index out of range: UMT_STATUS_BAD_MEMORY_IDX; sample runs without memory);
+// bit 30 set = sample b reads the row but another sample of the batch owns the write.
+constexpr int32_t ROW_NOT_OWNER = 1 << 30;
+
+__global__ void temporal_xforms_kernel(const float* prev_ext, unsigned long long* owner, unsigned epoch, int mem_rows,
+                                       const float* cam0, const int64_t* midx, const uint8_t* use, int bs, float* rel_xf,
+                                       int32_t* row_of, uint8_t* use_eff, int32_t* status) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= bs) return;
   const int64_t idx = midx[b];
@@ -242,29 +260,47 @@ __global__ void temporal_xforms_kernel(float* prev_ext, int mem_rows, const floa
   row_of[b] = okr ? (int32_t)idx : -1;
   float* o = rel_xf + b * 12;
   for (int i = 0; i < 12; ++i) o[i] = 0.f;
-  if (!okr) return;
-  if (use[b]) {
-    double pe[16], pinv[16], ce[16], rel[16];
-    load_mat4(prev_ext + idx * 16, pe);
-    load_mat4(cam0 + b * 16, ce);
-    mat4_inv(pe, pinv);
-    mat4_mul(ce, pinv, rel);
-    for (int i = 0; i < 12; ++i) o[i] = (float)rel[i];
+  uint8_t u = 0;
+  if (!okr) {
+    atomicOr(status, UMT_STATUS_BAD_MEMORY_IDX);
+  } else {
+    if (use[b]) {
+      double pe[16], pinv[16], ce[16], rel[16];
+      load_mat4(prev_ext + idx * 16, pe);
+      load_mat4(cam0 + b * 16, ce);
+      if (mat4_inv(pe, pinv)) {
+        mat4_mul(ce, pinv, rel);
+        for (int i = 0; i < 12; ++i) o[i] = (float)rel[i];
+        u = 1;
+      } else {      // torch.inverse raises here (temporal.py:66); the row is treated as use_memory = False and flagged
+        atomicOr(status, UMT_STATUS_SINGULAR_PREV_EXTRINSICS);
+      }
+    }
+    atomicMax(owner + idx, ((unsigned long long)epoch << 32) | (unsigned)b);
   }
-  for (int i = 0; i < 16; ++i) prev_ext[idx * 16 + i] = cam0[b * 16 + i];
+  use_eff[b] = u;
 }
 
-// tin_rows[b*36+p][0..17] = use ? FTL(rel, mem[idx]) : 0   (temporal.py:59-74, 83-85); mem is (rows,18,6,6)
-__global__ void temporal_gather_kernel(const float* mem, const float* rel_xf, const int32_t* row_of,
-                                       const uint8_t* use, int bs, float* tin, int tin_cs) {
+// tin_rows[b*36+p][0..17] = use ? FTL(rel, mem[idx]) : 0   (temporal.py:59-74, 83-85); mem is (rows,18,6,6).
+// Thread (c == 0, p < 16) of the winning sample also stores element p of prev_E[idx] = cur_E (temporal.py:77).
+__global__ void temporal_gather_kernel(const float* mem, float* prev_ext, const unsigned long long* owner, unsigned epoch,
+                                       const float* cam0, const float* rel_xf, int32_t* row_of, const uint8_t* use,
+                                       int bs, float* tin, int tin_cs) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= bs * 36 * 6) return;
   const int c = t % 6;
   const int p = (t / 6) % 36;
   const int b = t / (6 * 36);
   float x = 0.f, y = 0.f, z = 0.f;
-  const int row = row_of[b];
-  if (row >= 0 && use[b]) {
+  const int32_t ro = row_of[b];                    // launch 1 wrote plain rows; only this launch adds the bit
+  const bool has_row = ro >= 0;
+  const int row = ro & ~ROW_NOT_OWNER;
+  if (has_row && c == 0) {
+    const bool mine = owner[row] == (((unsigned long long)epoch << 32) | (unsigned)b);
+    if (mine && p < 16) prev_ext[(size_t)row * 16 + p] = cam0[b * 16 + p];
+    if (!mine && p == 35) row_of[b] = row | ROW_NOT_OWNER;      // read by temporal_split_kernel only
+  }
+  if (has_row && use[b]) {
     const float* m = mem + (size_t)row * 18 * 36;
     ftl_point(rel_xf + b * 12, m[c * 36 + p], m[(c + 6) * 36 + p], m[(c + 12) * 36 + p], x, y, z);
   }
@@ -272,13 +308,14 @@ __global__ void temporal_gather_kernel(const float* mem, const float* rel_xf, co
   o[c] = x; o[c + 6] = y; o[c + 12] = z;
 }
 
-int launch_temporal_gather(float* mem, float* prev_ext, int mem_rows, const float* cam0_ext,
-                           const int64_t* memory_idx, const uint8_t* use_memory, int bs, float* tin_rows,
-                           int tin_cs, float* rel_xf, int32_t* row_of, hipStream_t s) {
-  hipLaunchKernelGGL(temporal_xforms_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, prev_ext, mem_rows, cam0_ext,
-                     memory_idx, use_memory, bs, rel_xf, row_of);
-  hipLaunchKernelGGL(temporal_gather_kernel, dim3(grid_for((int64_t)bs * 36 * 6, 256)), dim3(256), 0, s, mem,
-                     rel_xf, row_of, use_memory, bs, tin_rows, tin_cs);
+int launch_temporal_gather(float* mem, float* prev_ext, unsigned long long* owner, unsigned epoch, int mem_rows,
+                           const float* cam0_ext, const int64_t* memory_idx, const uint8_t* use_memory, int bs,
+                           float* tin_rows, int tin_cs, float* rel_xf, int32_t* row_of, int32_t* status, hipStream_t s) {
+  uint8_t* use_eff = reinterpret_cast<uint8_t*>(rel_xf + (size_t)bs * 12);     // carve_head reserves bs bytes behind rel_xf
+  hipLaunchKernelGGL(temporal_xforms_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, prev_ext, owner, epoch, mem_rows,
+                     cam0_ext, memory_idx, use_memory, bs, rel_xf, row_of, use_eff, status);
+  hipLaunchKernelGGL(temporal_gather_kernel, dim3(grid_for((int64_t)bs * 36 * 6, 256)), dim3(256), 0, s, mem, prev_ext,
+                     owner, epoch, cam0_ext, rel_xf, row_of, use_eff, bs, tin_rows, tin_cs);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -294,7 +331,7 @@ __global__ void temporal_split_kernel(const float* tout, int tout_cs, float* mem
   const float v = tout[((size_t)b * 36 + p) * tout_cs + c];
   if (c < 18) {
     const int row = row_of[b];
-    if (row >= 0) mem[(size_t)row * 18 * 36 + c * 36 + p] = v;
+    if (row >= 0 && !(row & ROW_NOT_OWNER)) mem[(size_t)row * 18 * 36 + c * 36 + p] = v;      // the claiming sample only
   } else {
     out[((size_t)b * 36 + p) * out_cs + (c - 18)] = v;
   }
@@ -331,7 +368,8 @@ __global__ void skeleton_kernel(SkelParams p, const float* axes, const float* re
     s = fmaf(w[j * 6 + 5], r[j * 3 + 2], s);
   }
   const int c = o / 36, px = o % 36;
-  const float v = fmaxf((s + p.bias[o]) * p.scale[c] + p.shift[c], 0.f);
+  const float lin = (s + p.bias[o]) * p.scale[c] + p.shift[c];
+  const float v = lin != lin ? lin : fmaxf(lin, 0.f);      // ReLU that keeps a NaN, like torch's
   rows[((size_t)b * 36 + px) * cs + c0 + c] = v;
 }
 
@@ -427,10 +465,25 @@ __device__ inline void kabsch_rotation(const double* H, double* R) {
 }
 
 __global__ void decode_kernel(const float* raw, int nraw, int predict_scale, const float* cam0, const int64_t* hand_idx,
-                              int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales) {
+                              int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales,
+                              int32_t* status) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= bs) return;
   const float* r = raw + (size_t)b * nraw;
+  // torch's ReLU / MaxPool propagate NaN; the integer ReLU and the pooled max of the backbone kernels may drop one
+  // (conv_f32_common.h, stem.hip).  A non-finite regressor row is therefore reported, and the whole row of outputs
+  // is NaN, so that a corrupted crop or weight cannot come out as a plausible pose.
+  bool finite = true;
+  for (int i = 0; i < nraw; ++i) finite = finite && isfinite(r[i]);
+  if (!finite) {
+    if (status) atomicOr(status, UMT_STATUS_NONFINITE_OUTPUT);
+    const float q = __builtin_nanf("");
+    for (int i = 0; i < 22; ++i) joint_angles[b * 22 + i] = q;
+    for (int i = 0; i < 16; ++i) wrist_xfs[b * 16 + i] = q;
+    for (int i = 0; i < 21; ++i) sigmas[b * 21 + i] = q;
+    if (predict_scale) skel_scales[b] = q;
+    return;
+  }
   // regressor.py:76-85
   for (int i = 0; i < 20; ++i) joint_angles[b * 22 + i] = r[i];
   joint_angles[b * 22 + 20] = 0.f;
@@ -480,11 +533,12 @@ __global__ void decode_kernel(const float* raw, int nraw, int predict_scale, con
 }
 
 int launch_decode(const float* raw, int nraw, int predict_scale, const float* cam0_ext, const int64_t* hand_idx,
-                  int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales, hipStream_t s) {
+                  int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales, int32_t* status,
+                  hipStream_t s) {
   UMT_REQUIRE(nraw == (predict_scale ? 63 : 62), UMT_ERR_INVALID, "decode: nraw = %d", nraw);
   UMT_REQUIRE(!predict_scale || skel_scales, UMT_ERR_INVALID, "decode: scale head needs a skel_scales buffer");
   hipLaunchKernelGGL(decode_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, raw, nraw, predict_scale, cam0_ext,
-                     hand_idx, bs, joint_angles, wrist_xfs, sigmas, skel_scales);
+                     hand_idx, bs, joint_angles, wrist_xfs, sigmas, skel_scales, status);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -58,6 +58,9 @@ struct umt_model {
   std::vector<char> seen;
   bool finalized = false;
   int device = -1;
+  unsigned conv_flags = 0;   // CONV_* kernel-selection switches, read from the environment at umt_model_create
+  int stage1_sub = 0;        // UMT_STAGE1_SUB, likewise
+  int32_t* status = nullptr; // dev, UMT_STATUS_* bits OR-ed by the kernels (lives at the end of `slab`)
   float* slab = nullptr;   // all packed weights
   uint16_t* slab_h = nullptr;   // bf16 copies of the backbone conv weights (UMT_PREC_BF16)
   // network
@@ -71,18 +74,25 @@ struct umt_model {
   // temporal state (temporal.py:41-42)
   float* mem = nullptr;        // (rows,18,6,6)
   float* prev_ext = nullptr;   // (rows,4,4)
+  unsigned long long* mem_owner = nullptr;   // (rows): (epoch << 32 | sample) of the sample that last claimed the row
+  unsigned mem_epoch = 0;      // one per temporal step
   int mem_rows = 0;
   int mem_cap = 0;
-  // optional stage timing (umt_model_timing_*): event triples per umt_model_forward call
+  // optional stage timing (umt_model_timing_*): a ring of TIMING_RING event triples; a triple that is recycled is
+  // folded into the running sums first, so a long run with timing on holds a bounded number of events
   bool timing = false;
-  std::vector<hipEvent_t> ev_pool;   // 3 per recorded call
-  size_t ev_used = 0;
+  std::vector<hipEvent_t> ev_pool;   // 3 per slot
+  size_t ev_head = 0, ev_live = 0;   // oldest live slot, number of live slots
+  double t_backbone_ms = 0, t_forward_ms = 0;
+  int t_calls = 0;
   // optional per-launch timing of the backbone (umt_model_layer_timing_*): one event before the stem and one
   // after every launch; a mark names the launch that ended at the event of the same index
   struct LayerMark { char name[48]; double flop; };
   bool layer_timing = false;
   std::vector<hipEvent_t> lev_pool;
   std::vector<LayerMark> lev_marks;
+  struct LayerAcc { char name[48]; double flop, ms; int launches; };
+  std::vector<LayerAcc> lev_acc;     // finished passes, folded per schedule position
 };
 
 namespace umt {
@@ -177,6 +187,7 @@ static void pack_conv(const umt_model* m, std::vector<float>& host, std::vector<
   L->cout_w = round_up(cout, 32);
   L->stride = stride;
   L->relu = relu;
+  L->flags = m->conv_flags;
   const std::vector<float>& w = val(m, wkey);
   const int c8 = L->cin_s / 8;
   Packed p;
@@ -324,7 +335,7 @@ static int64_t carve_head(Carver& cv, int n, int bs, HeadWs* w) {
   w->crop_xf = cv.take<float>((int64_t)n * 12);
   w->sample_xf = cv.take<float>((int64_t)bs * 12);
   w->cam0 = cv.take<float>((int64_t)bs * 16);
-  w->rel_xf = cv.take<float>((int64_t)bs * 12);
+  w->rel_xf = cv.take<float>((int64_t)bs * 13);      // 12 floats per sample + one effective use_memory byte each
   w->views = cv.take<int32_t>(bs);
   w->row_of = cv.take<int32_t>(bs);
   w->cat = cv.take<float>(px * 144);
@@ -343,6 +354,36 @@ static int64_t carve_head(Carver& cv, int n, int bs, HeadWs* w) {
   return cv.off;
 }
 
+// ---- stage timing (measurement aid): a ring of event triples ----
+constexpr size_t TIMING_RING = 64;
+
+static int timing_fold_oldest(umt_model* m) {
+  hipEvent_t* e = &m->ev_pool[3 * m->ev_head];
+  float t1 = 0, t2 = 0;
+  UMT_CHECK_HIP(hipEventSynchronize(e[2]));
+  UMT_CHECK_HIP(hipEventElapsedTime(&t1, e[0], e[1]));
+  UMT_CHECK_HIP(hipEventElapsedTime(&t2, e[0], e[2]));
+  m->t_backbone_ms += t1;
+  m->t_forward_ms += t2;
+  m->t_calls += 1;
+  m->ev_head = (m->ev_head + 1) % TIMING_RING;
+  m->ev_live -= 1;
+  return 0;
+}
+
+// the next free triple; when the ring is full the oldest one (TIMING_RING calls back) is folded into the sums first
+static int timing_slot(umt_model* m, hipEvent_t** ev) {
+  while (m->ev_pool.size() < 3 * TIMING_RING) {
+    hipEvent_t e;
+    UMT_CHECK_HIP(hipEventCreate(&e));
+    m->ev_pool.push_back(e);
+  }
+  if (m->ev_live == TIMING_RING) UMT_TRY(timing_fold_oldest(m));
+  *ev = &m->ev_pool[3 * ((m->ev_head + m->ev_live) % TIMING_RING)];
+  m->ev_live += 1;
+  return 0;
+}
+
 static int check_ready(const umt_model* m) {
   UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
   UMT_REQUIRE(m->finalized, UMT_ERR_STATE, "model is not finalized (call umt_model_finalize first)");
@@ -354,8 +395,37 @@ static int check_ready(const umt_model* m) {
 
 // ---- per-launch timing of the backbone (measurement aid) ----
 // name == nullptr: the mark that opens a backbone pass.  flop: algorithmic, true channel counts.
+// Fold every recorded mark into the per-position sums (waits for the last event) and forget the marks, so the
+// event pool is reused from its start: a long run with layer timing on holds at most LAYER_MARK_CAP + one pass.
+static int layer_marks_fold(umt_model* m) {
+  if (m->lev_marks.empty()) return 0;
+  UMT_CHECK_HIP(hipEventSynchronize(m->lev_pool[m->lev_marks.size() - 1]));
+  size_t pos = 0;
+  for (size_t k = 0; k < m->lev_marks.size(); ++k) {
+    const umt_model::LayerMark& mk = m->lev_marks[k];
+    if (mk.flop < 0) { pos = 0; continue; }       // opening mark of a pass
+    UMT_REQUIRE(k > 0, UMT_ERR_STATE, "layer timing: launch mark without an opening mark");
+    float t = 0;
+    UMT_CHECK_HIP(hipEventElapsedTime(&t, m->lev_pool[k - 1], m->lev_pool[k]));
+    if (m->lev_acc.size() <= pos) {
+      umt_model::LayerAcc a{};
+      memcpy(a.name, mk.name, 48);
+      m->lev_acc.push_back(a);
+    }
+    m->lev_acc[pos].flop += mk.flop;
+    m->lev_acc[pos].ms += t;
+    m->lev_acc[pos].launches += 1;
+    ++pos;
+  }
+  m->lev_marks.clear();
+  return 0;
+}
+
+constexpr size_t LAYER_MARK_CAP = 1024;
+
 static int layer_mark(umt_model* m, hipStream_t s, const char* name, double flop) {
   if (!m->layer_timing) return 0;
+  if (!name && m->lev_marks.size() >= LAYER_MARK_CAP) UMT_TRY(layer_marks_fold(m));   // only between passes
   const size_t k = m->lev_marks.size();
   if (m->lev_pool.size() <= k) {
     hipEvent_t e;
@@ -422,14 +492,9 @@ static int run_blocks(umt_model* m, bool x3, size_t b0, size_t b1, int n, float*
   return 0;
 }
 
-static int stage1_sub() {
-  static const int v = getenv("UMT_STAGE1_SUB") ? atoi(getenv("UMT_STAGE1_SUB")) : 0;
-  return v;
-}
-
 static int backbone_rows(umt_model* m, bool x3, const float* images, int n, const BackboneWs& w, hipStream_t s) {
   float *x = w.a, *t = w.b, *y = w.c;
-  const int sub = stage1_sub();
+  const int sub = m->stage1_sub;
   size_t first = 0;
   UMT_TRY(layer_mark(m, s, nullptr, 0));
   if (sub > 0 && sub < n) {
@@ -504,7 +569,7 @@ static int run_blocks_bf16(umt_model* m, size_t b0, size_t b1, int n, uint16_t*&
 
 static int backbone_rows_bf16(umt_model* m, const float* images, int n, const BackboneWs& w, hipStream_t s) {
   uint16_t *x = (uint16_t*)w.a, *t = (uint16_t*)w.b, *y = (uint16_t*)w.c, *d = (uint16_t*)w.d;
-  const int sub = stage1_sub();
+  const int sub = m->stage1_sub;
   size_t first = 0;
   UMT_TRY(layer_mark(m, s, nullptr, 0));
   if (sub > 0 && sub < n) {
@@ -539,7 +604,7 @@ static int backbone_any(umt_model* m, int precision, const float* images, int n,
 // feat rows [n*36][72] -> fused features written into tin channels 18..89
 static int fuse_rows(umt_model* m, const float* feat, const float* K, const float* E, const int64_t* sr, int n, int bs,
                      const HeadWs& w, hipStream_t s) {
-  UMT_TRY(launch_fusion_xforms(K, E, sr, n, bs, w.crop_xf, w.sample_xf, w.views, s));
+  UMT_TRY(launch_fusion_xforms(K, E, sr, n, bs, w.crop_xf, w.sample_xf, w.views, m->status, s));
   UMT_TRY(launch_ftl_concat(feat, w.crop_xf, sr, w.views, n, bs, w.cat, s));
   UMT_TRY(launch_conv(m->fuse1, w.cat, bs, 6, 6, nullptr, w.f1, s));
   UMT_TRY(launch_conv(m->fuse2, w.f1, bs, 6, 6, nullptr, w.f2, s));
@@ -553,7 +618,10 @@ static int fuse_rows(umt_model* m, const float* feat, const float* K, const floa
 static int temporal_rows(umt_model* m, const float* cam0, const int64_t* midx, const uint8_t* use, int bs,
                          const HeadWs& w, float* out_rows, int out_cs, hipStream_t s) {
   UMT_REQUIRE(m->mem_rows > 0, UMT_ERR_STATE, "temporal: no memory rows reserved (umt_model_reserve_memory)");
-  UMT_TRY(launch_temporal_gather(m->mem, m->prev_ext, m->mem_rows, cam0, midx, use, bs, w.tin, 96, w.rel_xf, w.row_of, s));
+  m->mem_epoch += 1;                      // one claim epoch per step; 2^32 steps before it could wrap
+  if (m->mem_epoch == 0) m->mem_epoch = 1;
+  UMT_TRY(launch_temporal_gather(m->mem, m->prev_ext, m->mem_owner, m->mem_epoch, m->mem_rows, cam0, midx, use, bs, w.tin, 96,
+                                 w.rel_xf, w.row_of, m->status, s));
   UMT_TRY(launch_conv(m->temp[0], w.tin, bs, 6, 6, nullptr, w.t1, s));
   UMT_TRY(launch_conv(m->temp[1], w.t1, bs, 6, 6, nullptr, w.t2, s));
   UMT_TRY(launch_conv(m->temp[2], w.t2, bs, 6, 6, nullptr, w.t1, s));
@@ -581,7 +649,7 @@ static int regress_rows(umt_model* m, int head, const float* skel_axes, const fl
   UMT_TRY(launch_avgpool(w.rout, 64, nraw, bs, w.raw, s));
   if (raw_out) UMT_CHECK_HIP(hipMemcpyAsync(raw_out, w.raw, (size_t)bs * nraw * sizeof(float), hipMemcpyDeviceToDevice, s));
   UMT_TRY(launch_decode(w.raw, nraw, head == UMT_HEAD_PREDICT_SCALE, cam0, hand_idx, bs, joint_angles, wrist_xfs, sigmas,
-                        skel_scales, s));
+                        skel_scales, m->status, s));
   return 0;
 }
 
@@ -589,11 +657,13 @@ static int regress_rows(umt_model* m, int head, const float* skel_axes, const fl
 
 // =====================================================================================  C ABI
 extern "C" const char* umt_last_error(void) { return g_err; }
-extern "C" int umt_abi_version(void) { return 1; }
+extern "C" int umt_abi_version(void) { return UMT_ABI_VERSION; }
 
 extern "C" int umt_model_create(umt_model** out) {
   UMT_REQUIRE(out, UMT_ERR_INVALID, "umt_model_create: null out pointer");
   umt_model* m = new umt_model();
+  m->conv_flags = conv_flags_from_env();
+  m->stage1_sub = getenv("UMT_STAGE1_SUB") ? atoi(getenv("UMT_STAGE1_SUB")) : 0;
   build_spec(m);
   *out = m;
   return 0;
@@ -601,13 +671,14 @@ extern "C" int umt_model_create(umt_model** out) {
 
 extern "C" int umt_model_destroy(umt_model* m) {
   if (!m) return 0;
-  if (m->finalized) {
+  if (m->device >= 0) {      // set as soon as finalize starts to allocate; free whatever exists
     int prev = -1;
     if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(m->device) == hipSuccess) {
       if (m->slab) (void)hipFree(m->slab);
       if (m->slab_h) (void)hipFree(m->slab_h);
       if (m->mem) (void)hipFree(m->mem);
       if (m->prev_ext) (void)hipFree(m->prev_ext);
+      if (m->mem_owner) (void)hipFree(m->mem_owner);
       for (hipEvent_t e : m->ev_pool) (void)hipEventDestroy(e);
       for (hipEvent_t e : m->lev_pool) (void)hipEventDestroy(e);
       (void)hipSetDevice(prev);
@@ -656,20 +727,10 @@ extern "C" int umt_model_set_param(umt_model* m, const char* key, const void* ho
   return 0;
 }
 
-extern "C" int umt_model_finalize(umt_model* m, int device) {
-  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
-  UMT_REQUIRE(!m->finalized, UMT_ERR_STATE, "model already finalized");
-  for (size_t i = 0; i < m->spec.size(); ++i)
-    UMT_REQUIRE(m->seen[i], UMT_ERR_KEY, "Missing key in state_dict: \"%s\"", m->spec[i].key.c_str());
-  int ndev = 0;
-  UMT_CHECK_HIP(hipGetDeviceCount(&ndev));
-  UMT_REQUIRE(device >= 0 && device < ndev, UMT_ERR_INVALID, "device %d not available (%d devices)", device, ndev);
-  hipDeviceProp_t prop;
-  UMT_CHECK_HIP(hipGetDeviceProperties(&prop, device));
-  UMT_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, UMT_ERR_UNSUPPORTED,
-              "libumetrack_hip is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
-  UMT_CHECK_HIP(hipSetDevice(device));
-  UMT_TRY(conv_prepare_device());      // raise the dynamic-LDS limit of the kernels that need > 64 KB, once per device
+// packs and uploads with `device` current; on failure the caller (umt_model_finalize) releases what was allocated
+static int finalize_on_device(umt_model* m, int device) {
+  UMT_TRY(conv_prepare_device());      // raise the dynamic-LDS limit of the kernels that need > 64 KB (idempotent)
+  m->device = device;                  // from here on umt_model_destroy / the failure path free the slabs
 
   std::vector<float> host;
   std::vector<Packed> packed;
@@ -776,6 +837,8 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
       host[sk_off[3] + c] = be[c] - mu[c] * alpha;
     }
   }
+  const size_t status_off = host.size();      // UMT_STATUS_WORDS int32 status words, zero
+  host.resize(host.size() + 4, 0.f);
   // every packed array starts 16-B aligned: all sizes above are multiples of 4 floats
   for (const Packed& p : packed)
     UMT_REQUIRE(p.w_off % 4 == 0 && p.b_off % 4 == 0, UMT_ERR_STATE, "internal: packed offsets not 16-B aligned");
@@ -793,10 +856,40 @@ extern "C" int umt_model_finalize(umt_model* m, int device) {
   for (const PackedH& p : packed_x3) p.layer->wx3 = m->slab_h + p.off;
   m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3]};
   m->skel = SkelParams{m->slab + sk_off[0], m->slab + sk_off[1], m->slab + sk_off[2], m->slab + sk_off[3]};
-  m->device = device;
-  m->finalized = true;
-  std::vector<std::vector<float>>().swap(m->values);
+  m->status = reinterpret_cast<int32_t*>(m->slab + status_off);
   return 0;
+}
+
+extern "C" int umt_model_finalize(umt_model* m, int device) {
+  UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
+  UMT_REQUIRE(!m->finalized, UMT_ERR_STATE, "model already finalized");
+  for (size_t i = 0; i < m->spec.size(); ++i)
+    UMT_REQUIRE(m->seen[i], UMT_ERR_KEY, "Missing key in state_dict: \"%s\"", m->spec[i].key.c_str());
+  int ndev = 0, prev = -1;
+  UMT_CHECK_HIP(hipGetDeviceCount(&ndev));
+  UMT_REQUIRE(device >= 0 && device < ndev, UMT_ERR_INVALID, "device %d not available (%d devices)", device, ndev);
+  hipDeviceProp_t prop;
+  UMT_CHECK_HIP(hipGetDeviceProperties(&prop, device));
+  UMT_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, UMT_ERR_UNSUPPORTED,
+              "libumetrack_hip is built for gfx950 only, device %d is %s", device, prop.gcnArchName);
+  UMT_CHECK_HIP(hipGetDevice(&prev));
+  UMT_CHECK_HIP(hipSetDevice(device));
+  const int rc = finalize_on_device(m, device);
+  if (rc != 0) {      // leave the handle as it was before the call (the error text is already set); a retry packs afresh
+    if (m->slab) (void)hipFree(m->slab);
+    if (m->slab_h) (void)hipFree(m->slab_h);
+    m->slab = nullptr;
+    m->slab_h = nullptr;
+    m->status = nullptr;
+    m->device = -1;
+    m->blocks.clear();
+    m->block_hw.clear();
+  } else {
+    m->finalized = true;
+    std::vector<std::vector<float>>().swap(m->values);
+  }
+  (void)hipSetDevice(prev);      // the caller's current device is left as it was
+  return rc;
 }
 
 extern "C" int umt_model_reserve_memory(umt_model* m, int rows, void* stream) {
@@ -807,8 +900,16 @@ extern "C" int umt_model_reserve_memory(umt_model* m, int rows, void* stream) {
   if (rows > m->mem_cap) {
     const int cap = rows > 2 * m->mem_cap ? rows : 2 * m->mem_cap;
     float *nm = nullptr, *np = nullptr;
-    UMT_CHECK_HIP(hipMalloc((void**)&nm, (size_t)cap * 18 * 36 * sizeof(float)));
-    UMT_CHECK_HIP(hipMalloc((void**)&np, (size_t)cap * 16 * sizeof(float)));
+    unsigned long long* no = nullptr;
+    hipError_t e1 = hipMalloc((void**)&nm, (size_t)cap * 18 * 36 * sizeof(float));
+    hipError_t e2 = e1 == hipSuccess ? hipMalloc((void**)&np, (size_t)cap * 16 * sizeof(float)) : e1;
+    hipError_t e3 = e2 == hipSuccess ? hipMalloc((void**)&no, (size_t)cap * sizeof(unsigned long long)) : e2;
+    if (e3 != hipSuccess) {      // nothing is kept of a failed growth; the old state stays valid
+      if (nm) (void)hipFree(nm);
+      if (np) (void)hipFree(np);
+      return set_error(UMT_ERR_HIP, "reserve_memory: hipMalloc for %d rows failed: %s", cap, hipGetErrorString(e3));
+    }
+    UMT_CHECK_HIP(hipMemsetAsync(no, 0, (size_t)cap * sizeof(unsigned long long), s));   // epoch 0 is never used
     if (m->mem_rows > 0) {
       UMT_CHECK_HIP(hipMemcpyAsync(nm, m->mem, (size_t)m->mem_rows * 18 * 36 * sizeof(float), hipMemcpyDeviceToDevice, s));
       UMT_CHECK_HIP(hipMemcpyAsync(np, m->prev_ext, (size_t)m->mem_rows * 16 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -816,8 +917,10 @@ extern "C" int umt_model_reserve_memory(umt_model* m, int rows, void* stream) {
     UMT_CHECK_HIP(hipStreamSynchronize(s));   // old buffers are freed below; growth is rare (per new hand slot)
     if (m->mem) UMT_CHECK_HIP(hipFree(m->mem));
     if (m->prev_ext) UMT_CHECK_HIP(hipFree(m->prev_ext));
+    if (m->mem_owner) UMT_CHECK_HIP(hipFree(m->mem_owner));
     m->mem = nm;
     m->prev_ext = np;
+    m->mem_owner = no;
     m->mem_cap = cap;
   }
   // new rows start at zero (temporal.py:106-120)
@@ -969,13 +1072,7 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
   const int cs = head == UMT_HEAD_KNOWN_SKELETON ? 80 : 72;
   hipEvent_t* ev = nullptr;
   if (m->timing) {
-    while (m->ev_pool.size() < m->ev_used + 3) {
-      hipEvent_t e;
-      UMT_CHECK_HIP(hipEventCreate(&e));
-      m->ev_pool.push_back(e);
-    }
-    ev = &m->ev_pool[m->ev_used];
-    m->ev_used += 3;
+    UMT_TRY(timing_slot(m, &ev));
     UMT_CHECK_HIP(hipEventRecord(ev[0], s));
   }
   UMT_TRY(backbone_any(m, precision, images, n, bw, s));
@@ -993,25 +1090,19 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
 extern "C" int umt_model_timing_enable(umt_model* m, int on) {
   UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
   m->timing = on != 0;
-  m->ev_used = 0;
+  m->ev_head = m->ev_live = 0;      // events still in flight from an earlier enable are simply recorded over later
+  m->t_backbone_ms = m->t_forward_ms = 0;
+  m->t_calls = 0;
   return 0;
 }
 
 extern "C" int umt_model_timing_read(umt_model* m, double* backbone_ms, double* forward_ms, int* calls) {
   UMT_TRY(check_ready(m));
   UMT_REQUIRE(backbone_ms && forward_ms && calls, UMT_ERR_INVALID, "null argument");
-  double b = 0, f = 0;
-  for (size_t i = 0; i + 2 < m->ev_used + 0 && i + 2 < m->ev_pool.size() + 0; i += 3) {
-    float t1 = 0, t2 = 0;
-    UMT_CHECK_HIP(hipEventSynchronize(m->ev_pool[i + 2]));
-    UMT_CHECK_HIP(hipEventElapsedTime(&t1, m->ev_pool[i], m->ev_pool[i + 1]));
-    UMT_CHECK_HIP(hipEventElapsedTime(&t2, m->ev_pool[i], m->ev_pool[i + 2]));
-    b += t1;
-    f += t2;
-  }
-  *backbone_ms = b;
-  *forward_ms = f;
-  *calls = (int)(m->ev_used / 3);
+  while (m->ev_live > 0) UMT_TRY(timing_fold_oldest(m));
+  *backbone_ms = m->t_backbone_ms;
+  *forward_ms = m->t_forward_ms;
+  *calls = m->t_calls;
   return 0;
 }
 
@@ -1019,6 +1110,17 @@ extern "C" int umt_model_layer_timing_enable(umt_model* m, int on) {
   UMT_REQUIRE(m, UMT_ERR_INVALID, "null model handle");
   m->layer_timing = on != 0;
   m->lev_marks.clear();
+  m->lev_acc.clear();
+  return 0;
+}
+
+extern "C" int umt_model_status(umt_model* m, int32_t* status_host, int clear, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(status_host, UMT_ERR_INVALID, "model_status: null output");
+  hipStream_t s = (hipStream_t)stream;
+  UMT_CHECK_HIP(hipMemcpyAsync(status_host, m->status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  if (clear) UMT_CHECK_HIP(hipMemsetAsync(m->status, 0, sizeof(int32_t), s));
+  UMT_CHECK_HIP(hipStreamSynchronize(s));
   return 0;
 }
 
@@ -1027,23 +1129,16 @@ extern "C" int umt_model_layer_timing_read(umt_model* m, int max_layers, char* n
   UMT_TRY(check_ready(m));
   UMT_REQUIRE(max_layers > 0 && names && flop && ms && launches && n_layers, UMT_ERR_INVALID, "layer_timing_read: bad argument");
   // launch k of a backbone pass is aggregated with launch k of every other pass (the schedule is fixed per precision)
-  int pos = 0, count = 0;
+  UMT_TRY(layer_marks_fold(m));
   for (int i = 0; i < max_layers; ++i) { flop[i] = 0; ms[i] = 0; launches[i] = 0; names[(size_t)i * 48] = 0; }
-  if (!m->lev_marks.empty()) UMT_CHECK_HIP(hipEventSynchronize(m->lev_pool[m->lev_marks.size() - 1]));
-  for (size_t k = 0; k < m->lev_marks.size(); ++k) {
-    const umt_model::LayerMark& mk = m->lev_marks[k];
-    if (mk.flop < 0) { pos = 0; continue; }       // opening mark of a pass
-    UMT_REQUIRE(k > 0, UMT_ERR_STATE, "layer_timing_read: launch mark without an opening mark");
-    if (pos < max_layers) {
-      float t = 0;
-      UMT_CHECK_HIP(hipEventElapsedTime(&t, m->lev_pool[k - 1], m->lev_pool[k]));
-      if (launches[pos] == 0) memcpy(names + (size_t)pos * 48, mk.name, 48);
-      flop[pos] += mk.flop;
-      ms[pos] += t;
-      launches[pos] += 1;
-      if (pos + 1 > count) count = pos + 1;
-    }
-    ++pos;
+  int count = 0;
+  for (size_t pos = 0; pos < m->lev_acc.size() && (int)pos < max_layers; ++pos) {
+    const umt_model::LayerAcc& a = m->lev_acc[pos];
+    memcpy(names + pos * 48, a.name, 48);
+    flop[pos] = a.flop;
+    ms[pos] = a.ms;
+    launches[pos] = a.launches;
+    count = (int)pos + 1;
   }
   *n_layers = count;
   return 0;

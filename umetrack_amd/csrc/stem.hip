@@ -36,11 +36,17 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __
   const int yo0 = band * STEM_ROWS;
   const float* src = images + (size_t)img * 96 * 96;
   // input rows 2*yo0 - 1 .. 2*yo0 + 8 (zero outside the crop), 24 float4 per row
+  // torch's convolution, ReLU and MaxPool propagate NaN; the pooled max below starts from 0 and v_max drops a NaN
+  // operand.  Non-finite input pixels are therefore detected here, once per staged element, and only a band that
+  // holds one takes the per-patch check in the item loop (which writes canonical NaNs for every pooled pixel whose
+  // 4x4 patch touches it, the pixels torch would make NaN; an infinite input is treated the same way).
+  int bad = 0;
   for (int i = tid; i < STEM_IN_ROWS * 24; i += 256) {
     const int r = i / 24, c4 = i - r * 24;
     const int y = 2 * yo0 - 1 + r;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (y >= 0 && y < 96) v = *reinterpret_cast<const float4*>(src + y * 96 + 4 * c4);
+    bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
     float* d = sin_ + r * STEM_LDW + 2 + 4 * c4;     // 8-byte aligned
     *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
     *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
@@ -49,7 +55,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __
     float* d = sin_ + tid * STEM_LDW;
     d[0] = d[1] = d[98] = d[99] = 0.f;
   }
-  __syncthreads();
+  const int any_bad = __syncthreads_or(bad);
 #pragma unroll 1
   for (int it = 0; it < STEM_ROWS * 48 * 4 / 256; ++it) {
     const int item = tid + 256 * it;
@@ -94,6 +100,16 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __
         }
       res[c] = best.x;
       res[c + 1] = best.y;
+    }
+    if (any_bad) {        // rare: uniform over the workgroup
+      bool nf = false;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) nf = nf || !isfinite(patch[dy][dx]);
+      if (nf)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) res[c] = __builtin_nanf("");
     }
     const size_t pix = ((size_t)img * 48 + yo0 + ry) * 48 + xo;
     if (OUT_BF16) {

@@ -39,18 +39,29 @@ int set_error(int code, const char* fmt, ...);
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once per
-// device.  `done` is the caller's per-kernel table (one flag per device); conv_prepare_device() raises the
-// attribute of every such kernel at umt_model_finalize, so the launch path normally only reads the flag.
-static inline int ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned char (&done)[64]) {
-  int dev = 0;
-  UMT_CHECK_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64 || !done[dev]) {
-    UMT_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    if (dev >= 0 && dev < 64) done[dev] = 1;
-  }
+// device.  conv_prepare_device() does that for every such kernel, for the current device; umt_model_finalize calls
+// it (and tools/conv_bench.hip, which launches without a model).  The call is idempotent and the library keeps no
+// record of it: there is no process-wide mutable state behind the launch path.
+static inline int raise_dynamic_lds(const void* kernel, size_t bytes) {
+  UMT_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   return 0;
 }
-int conv_prepare_device();      // conv_igemm.hip + conv_thin.hip: raise the attribute for the current device
+int conv_prepare_device();      // conv_igemm.hip + conv_thin.hip + conv_x3.hip: for the current device
+
+// Kernel-selection switches (diagnostics: A/B profiling and the bit-identity tests).  umt_model_create reads them
+// from the environment ONCE PER MODEL HANDLE and umt_model_finalize copies them into every ConvLayer of that
+// handle; the launchers read ConvLayer::flags only.
+enum : unsigned {
+  CONV_NO_THIN = 1u,        // UMT_CONV_NOTHIN: bf16 stages 1-3 on conv3x3s1_halo_bf16 instead of conv_thin.hip's kernels
+  CONV_NO_FUSE = 2u,        // UMT_CONV_NOFUSE: stage-1 BasicBlocks as two launches instead of block32_fused_bf16
+  CONV_NO_STREAM128 = 4u,   // UMT_CONV_NOSTREAM128
+  CONV_NO_THIN_F32 = 8u,    // UMT_CONV_NOTHIN_F32: fp32 stage 1 on conv3x3s1_halo_f32 instead of conv3x3_wlds32_f32
+  CONV_GATHER = 16u,        // UMT_CONV_GATHER: every fp32 convolution on the per-tap gather kernel
+  CONV_NO_S2 = 32u,         // UMT_CONV_NOS2: no fused stride-2 + down-sample kernel
+  CONV_X3_NO_S2 = 64u,      // UMT_X3_NOS2
+  CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
+};
+unsigned conv_flags_from_env();
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 #ifdef __HIPCC__
@@ -91,6 +102,7 @@ struct ConvLayer {
   const float* shift = nullptr;  // dev [cout_w]
   const uint16_t* wh = nullptr;  // dev, bf16 packed [tap][cin_s/16][2][cout_w][8] (backbone layers only)
   const uint16_t* wx3 = nullptr; // dev, three-way bf16 split [tap][cin_s/16][plane][2][cout_w][8] (backbone 3x3 layers)
+  unsigned flags = 0;            // CONV_* kernel-selection switches of the owning model handle
 };
 
 // conv_igemm.hip
@@ -119,7 +131,6 @@ int launch_conv_s2_fused_x3(const ConvLayer& c1, const ConvLayer* ds, const floa
                             float* ds_out, hipStream_t stream);
 
 // conv_thin.hip: persistent bf16 kernel for the 32->32 stride-1 3x3 layers (weights in registers)
-extern int g_conv_thin;
 bool conv_thin_applicable(const ConvLayer& L, int w);
 int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w, const uint16_t* residual,
                           uint16_t* out, hipStream_t stream);
@@ -151,16 +162,17 @@ int launch_zero_channels(float* rows, int cs, int c0, int c, int64_t nrows, hipS
 // per-sample transforms for fusion: to_canon (per crop, 12 floats [R|t] rows) and out_xf (per sample)
 int launch_fusion_xforms(const float* intrinsics, const float* extrinsics, const int64_t* sample_range,
                          int n, int bs, float* crop_xf, float* sample_xf, int32_t* sample_views,
-                         hipStream_t s);
+                         int32_t* status, hipStream_t s);
 int launch_ftl_concat(const float* feat_rows, const float* crop_xf, const int64_t* sample_range,
                       const int32_t* sample_views, int n, int bs, float* cat_rows, hipStream_t s);
 int launch_ftl_select(const float* conv_rows, const float* feat_rows, const float* sample_xf,
                       const int64_t* sample_range, const int32_t* sample_views, int n, int bs,
                       float* out_rows, int out_cs, int out_c0, hipStream_t s);
-// rel_xf: scratch [bs][12] floats, row_of: scratch [bs] int32 (validated memory row per sample)
-int launch_temporal_gather(float* mem, float* prev_ext, int mem_rows, const float* cam0_ext,
-                           const int64_t* memory_idx, const uint8_t* use_memory, int bs,
-                           float* tin_rows, int tin_cs, float* rel_xf, int32_t* row_of, hipStream_t s);
+// rel_xf: scratch [bs][12] floats + bs bytes, row_of: scratch [bs] int32 (validated memory row per sample);
+// owner: [mem_rows] claim words of the model handle, epoch: this step's claim epoch; status: UMT_STATUS_* word
+int launch_temporal_gather(float* mem, float* prev_ext, unsigned long long* owner, unsigned epoch, int mem_rows,
+                           const float* cam0_ext, const int64_t* memory_idx, const uint8_t* use_memory, int bs,
+                           float* tin_rows, int tin_cs, float* rel_xf, int32_t* row_of, int32_t* status, hipStream_t s);
 int launch_temporal_split(const float* tout_rows, int tout_cs, float* mem, const int32_t* row_of, int bs,
                           float* out_rows, int out_cs, hipStream_t s);
 struct SkelParams {
@@ -174,7 +186,7 @@ int launch_skeleton(const SkelParams& p, const float* axes, const float* rest, i
 int launch_avgpool(const float* rows, int cs, int c, int bs, float* raw, hipStream_t s);
 int launch_decode(const float* raw, int nraw, int predict_scale, const float* cam0_ext,
                   const int64_t* hand_idx, int bs, float* joint_angles, float* wrist_xfs,
-                  float* sigmas, float* skel_scales, hipStream_t s);
+                  float* sigmas, float* skel_scales, int32_t* status, hipStream_t s);
 int launch_gather_cam0(const float* extrinsics, const int64_t* sample_range, int n, int bs,
                        float* cam0, hipStream_t s);
 

@@ -118,6 +118,7 @@ __device__ inline void quantise_map(float mx, float my, int& sx, int& sy) {
 
 
 // window (u,v) of the crop camera -> window coordinates in the fisheye source, as float32
+template <bool DEPTH_CHECK = true>
 __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v, float& mx, float& my) {
   // camera.py:275-281 + PerspectiveProjection.unproject (camera.py:68-75) + affine.normalized
   double qx = ((double)u - d.cx) / d.fx, qy = ((double)v - d.cy) / d.fy;
@@ -146,7 +147,7 @@ __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v,
   double dx = ux + (2 * s.p2 * xy + s.p1 * (rr + 2 * x2));
   double dy = uy + (2 * s.p1 * xy + s.p2 * (rr + 2 * y2));
   double ox = dx * s.fx + s.cx, oy = dy * s.fy + s.cy;
-  if (z < 0) { ox = -1.0; oy = -1.0; }   // depth check, tracker.py:71-73
+  if (DEPTH_CHECK && z < 0) { ox = -1.0; oy = -1.0; }   // depth check, tracker.py:71-73
   mx = (float)ox;
   my = (float)oy;
 }
@@ -204,7 +205,7 @@ __device__ inline void load_cams(const double* __restrict__ src_cams, const doub
 
 // MODE: UMT_WARP_CV2_FIXED_POINT (float32 map + float64 re-evaluation queue), UMT_WARP_FLOAT,
 // UMT_WARP_CV2_FIXED_POINT_F64 (every pixel in float64)
-template <int MODE>
+template <int MODE, bool DEPTH_CHECK = true>
 __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __restrict__ src_images,
                                                             const int64_t* __restrict__ src_offset,
                                                             const int32_t* __restrict__ src_pitch,
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
       if (p < npx) {
         const int v = p / out_w, u = p - v * out_w;
         float mx, my;
-        map_point(s, d, u, v, mx, my);
+        map_point<DEPTH_CHECK>(s, d, u, v, mx, my);
         if (CV2) {
           quantise_map(mx, my, sxs[i], sys[i]);
         } else {
@@ -429,12 +430,17 @@ extern "C" int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offs
   UMT_REQUIRE(n > 0 && out_h > 0 && out_w >= 4, UMT_ERR_INVALID, "warp: n=%d out=%dx%d (width must be >= 4)", n, out_h, out_w);
   UMT_REQUIRE(out_h * out_w <= WARP_MAX_PX * WARP_THREADS, UMT_ERR_UNSUPPORTED,
               "warp: crops larger than %d pixels are not supported (got %dx%d)", WARP_MAX_PX * WARP_THREADS, out_w, out_h);
+  const bool depth_check = (mode & UMT_WARP_NO_DEPTH_CHECK) == 0;
+  mode &= ~UMT_WARP_NO_DEPTH_CHECK;
   UMT_REQUIRE(mode == UMT_WARP_CV2_FIXED_POINT || mode == UMT_WARP_FLOAT || mode == UMT_WARP_CV2_FIXED_POINT_F64,
               UMT_ERR_INVALID, "warp: mode %d", mode);
   UMT_REQUIRE(src_images && src_offset && src_pitch && src_cams && dst_cams && out, UMT_ERR_INVALID, "warp: null pointer");
+  // depth_check=False (tracker.py:59, never used by the reference's own callers) runs every pixel in float64
+  if (!depth_check && mode == UMT_WARP_CV2_FIXED_POINT) mode = UMT_WARP_CV2_FIXED_POINT_F64;
   auto kern = mode == UMT_WARP_CV2_FIXED_POINT ? warp_kernel<UMT_WARP_CV2_FIXED_POINT>
-              : mode == UMT_WARP_FLOAT         ? warp_kernel<UMT_WARP_FLOAT>
-                                               : warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64>;
+              : mode == UMT_WARP_FLOAT         ? (depth_check ? warp_kernel<UMT_WARP_FLOAT> : warp_kernel<UMT_WARP_FLOAT, false>)
+              : depth_check                    ? warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64>
+                                               : warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64, false>;
   hipLaunchKernelGGL(kern, dim3(n), dim3(WARP_THREADS), WARP_LDS_BYTES, (hipStream_t)stream, src_images, src_offset,
                      src_pitch, src_cams, dst_cams, out_h, out_w, out);
   UMT_CHECK_HIP(hipGetLastError());

@@ -151,11 +151,35 @@ def find_result_files(output_dir: str) -> List[str]:
     return sorted(out)
 
 
+class _ArraysOnlyUnpickler(pickle.Unpickler):
+    """Result files are pickles of a dict of three numpy arrays (run_eval_known_skeleton.py:92-100).  A pickle
+    can name any callable; this loader resolves only what numpy arrays need and refuses everything else, so a
+    tampered or foreign result file cannot execute code."""
+    _ALLOWED = {("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) not in self._ALLOWED:
+            raise pickle.UnpicklingError(f"result file refers to {module}.{name}: only numpy arrays are accepted")
+        return super().find_class(module, name)
+
+
 def load_result(path: str) -> Dict[str, np.ndarray]:
-    """Result files are this package's own output (or the reference scripts'); like load_eval.py:55-56
-    they are pickles despite the .npy suffix."""
+    """Result files are this package's own output or the reference scripts'; like load_eval.py:55-56 they are
+    pickles despite the .npy suffix.  Loaded with an unpickler restricted to numpy arrays; the three fields are
+    checked for type and shape."""
     with open(path, "rb") as fp:
-        return pickle.load(fp)
+        d = _ArraysOnlyUnpickler(fp).load()
+    if not isinstance(d, dict):
+        raise pickle.UnpicklingError(f"{path}: expected a dict of arrays, got {type(d).__name__}")
+    for key in ("tracked_keypoints", "gt_keypoints", "valid_tracking"):
+        if not isinstance(d.get(key), np.ndarray):
+            raise pickle.UnpicklingError(f"{path}: field {key!r} is missing or not a numpy array")
+    if d["tracked_keypoints"].shape != d["gt_keypoints"].shape or d["valid_tracking"].shape != d["gt_keypoints"].shape[:2]:
+        raise pickle.UnpicklingError(f"{path}: inconsistent array shapes")
+    return d
 
 
 def aggregate_metrics(output_dir: str, files: Optional[Sequence[str]] = None, reduce_over_ranks: bool = False,
@@ -164,7 +188,8 @@ def aggregate_metrics(output_dir: str, files: Optional[Sequence[str]] = None, re
     ``reduce_over_ranks`` every rank passes its own ``files`` and all ranks get the global result."""
     if files is None:
         files = find_result_files(output_dir)
-    total = torch.zeros(108, dtype=torch.float64, device="cuda")
+    # a rank without files still takes part in the all-reduce, with zeros on the device the collective runs on
+    total = torch.zeros(108, dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
     for f in files:
         d = load_result(f)
         if d["valid_tracking"].shape[1] == 0:

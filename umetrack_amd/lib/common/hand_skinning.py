@@ -14,15 +14,28 @@ from .hand import HandModel
 
 def skin_landmarks(hand_model: HandModel, joint_angles: torch.Tensor, wrist_transforms: torch.Tensor,
                    hand_idx: Optional[torch.Tensor] = None, mirror_right: bool = False,
-                   wrist_translation_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   wrist_translation_scale: float = 1.0, out: Optional[torch.Tensor] = None,
+                   status: Optional[torch.Tensor] = None) -> torch.Tensor:
     """joint_angles [...,22], wrist_transforms [...,4,4] -> landmarks [...,21,3] (float32, on the GPU).
 
     Model fields either carry the same leading dims or none (one shared model).
     ``hand_idx`` / ``mirror_right`` fold in the right-hand mirror of
     landmarks_from_hand_pose (perspective_crop.py:46-49); ``wrist_translation_scale``
     folds in the m->mm step of the tracker (tracker.py:258).
+
+    Bone indices: the reference scatters the blend weights through a flattened index
+    (hand_skinning.py:87-94), so an index outside [0, 16] corrupts a neighbouring landmark or raises
+    IndexError.  Here a host-resident index tensor is checked before the launch (IndexError); for a
+    device-resident one the kernel writes NaN landmarks and ORs UMT_STATUS_BAD_BONE_INDEX (16) into
+    ``status`` (int32[1] on the device) when one is given.
     """
     dev = nat.require_gpu(joint_angles.device if joint_angles.is_cuda else None)
+    idx_t, w_t = hand_model.landmark_rest_bone_indices, hand_model.landmark_rest_bone_weights
+    if not (isinstance(idx_t, torch.Tensor) and idx_t.is_cuda):        # 63 integers per model: checked on the host
+        ih, wh = torch.as_tensor(idx_t), torch.as_tensor(w_t).cpu()
+        bad = ((ih < 0) | (ih > 16)) & (wh != 0)
+        if bool(bad.any()):
+            raise IndexError(f"landmark_rest_bone_indices: index {int(ih[bad][0])} is out of bounds for 17 bone frames")
     lead = tuple(joint_angles.shape[:-1])
     f32 = torch.float32
     ja = nat.dev_tensor(joint_angles, f32, dev).reshape(-1, 22)
@@ -55,6 +68,7 @@ def skin_landmarks(hand_model: HandModel, joint_angles: torch.Tensor, wrist_tran
     with torch.cuda.device(dev):
         nat.check(nat.lib().umt_fk_landmarks(nat.ptr(ja), nat.ptr(wr), nat.ptr(axes), nat.ptr(rest), nat.ptr(lm),
                                              nat.ptr(lw), nat.ptr(li), n_model, nat.ptr(hidx), int(mirror_right),
-                                             float(wrist_translation_scale), b, nat.ptr(out), nat.stream_ptr(dev)),
+                                             float(wrist_translation_scale), b, nat.ptr(out), nat.ptr(status),
+                                             nat.stream_ptr(dev)),
                   "umt_fk_landmarks")
     return out.reshape(lead + (21, 3))

@@ -145,6 +145,22 @@ class UmeTrackModel:
             nat.check(L.umt_model_read_memory(self._h, nat.ptr(mem), nat.ptr(prev), nat.stream_ptr(self._device)))
         return mem, prev
 
+    def status(self, clear: bool = True) -> int:
+        """The UMT_STATUS_* bits the kernels of this model have raised (one 4-byte copy + stream sync)."""
+        word = ctypes.c_int32(0)
+        with torch.cuda.device(self._device):
+            nat.check(nat.lib().umt_model_status(self._h, ctypes.byref(word), int(clear), nat.stream_ptr(self._device)),
+                      "umt_model_status")
+        return int(word.value)
+
+    def check_status(self) -> None:
+        """Raise where the reference would have raised inside the forward pass (torch.inverse on a singular
+        matrix, an index out of range) or where the outputs are not finite.  Call it wherever results reach the
+        host anyway: it synchronises the stream."""
+        bits = self.status(clear=True)
+        if bits:
+            raise nat.UmtError("; ".join(msg for bit, msg in nat.STATUS_BITS.items() if bits & bit))
+
     def timing_enable(self, on: bool = True) -> None:
         nat.check(nat.lib().umt_model_timing_enable(self._h, int(on)))
 

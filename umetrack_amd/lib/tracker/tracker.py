@@ -79,11 +79,13 @@ def _pack_views(views, pairs, device):
 def _warp_image(src_camera: camera.CameraModel, dst_camera: camera.CameraModel, src_image: np.ndarray,
                 interpolation: int = INTER_LINEAR, depth_check: bool = True) -> np.ndarray:
     """Single-image form of the warp (tracker.py:54-80): uint8 in, uint8 out, on the GPU."""
-    if interpolation != INTER_LINEAR or not depth_check:
-        raise NotImplementedError("only INTER_LINEAR with depth_check=True (the reference's call) is provided")
+    if interpolation != INTER_LINEAR:
+        raise NotImplementedError("only cv2.INTER_LINEAR (the reference's own call, and the only sampling whose "
+                                  "fixed-point arithmetic is restated here) is provided")
     view = ViewData(src_image, src_camera, 0.0)
     flat, offs, pitch, src, dst = _pack_views([view], [(0, dst_camera)], "cuda")
-    out = gpu_warp.warp_crops(flat, offs, pitch, src, dst, (dst_camera.height, dst_camera.width), gpu_warp.MODE_CV2)
+    mode = gpu_warp.MODE_CV2 if depth_check else gpu_warp.MODE_CV2 | gpu_warp.NO_DEPTH_CHECK
+    out = gpu_warp.warp_crops(flat, offs, pitch, src, dst, (dst_camera.height, dst_camera.width), mode)
     return torch.round(out[0] * 255.0).to(torch.uint8).cpu().numpy().astype(src_image.dtype)
 
 
@@ -100,8 +102,12 @@ class HandTracker:
         self._warp_mode = opts.warp_mode
         self._valid_tracking_history = np.zeros(2, dtype=bool)
 
-    def reset_history(self) -> None:
+    def reset_history(self, clear_model_memory: bool = False) -> None:
+        """tracker.py:98-99 clears the tracking history only (the next frame runs with use_memory=False, which
+        neutralises the module memory).  ``clear_model_memory`` additionally drops the model's temporal rows."""
         self._valid_tracking_history[:] = False
+        if clear_model_memory:
+            self._model.reset_memory()
 
     def gen_crop_cameras(self, cameras: List[camera.CameraModel], camera_angles: List[float], hand_model: HandModel,
                          gt_tracking: Dict[int, SingleHandPose],
@@ -177,6 +183,9 @@ class HandTracker:
         """tracker.py:249-291: metres -> millimetres, per-hand dicts, tracking history update."""
         angles = out.joint_angles.cpu().numpy()
         wrists = out.wrist_xfs.cpu().numpy()
+        check = getattr(self._model, "check_status", None)
+        if check is not None:               # the reference raises inside the forward pass; here after the copy-out
+            check()
         wrists[..., :3, 3] *= M_TO_MM
         scales = None if out.skel_scales is None else out.skel_scales.cpu().numpy()
         poses, views, pred_scales = {}, {}, {}

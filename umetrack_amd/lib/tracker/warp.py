@@ -17,6 +17,7 @@ DST_CAM_WORDS = 20   # fx,fy,cx,cy, cam_to_world(16)
 MODE_CV2 = nat.WARP_CV2_FIXED_POINT
 MODE_FLOAT = nat.WARP_FLOAT
 MODE_CV2_F64 = nat.WARP_CV2_FIXED_POINT_F64      # every map pixel in float64 (MODE_CV2 is bit-identical, faster)
+NO_DEPTH_CHECK = nat.WARP_NO_DEPTH_CHECK         # OR into the mode: _warp_image(depth_check=False), tracker.py:59,71-73
 
 
 def pack_fisheye(width, height, f, c, coeffs: Sequence[float], cam_to_world) -> np.ndarray:
