@@ -21,6 +21,7 @@ import json
 import os
 import sys
 import time
+from types import SimpleNamespace
 
 import numpy as np
 import torch
@@ -126,10 +127,18 @@ class Pipeline:
         self.valid = torch.ones(wl.n_rec, 2, T, dtype=torch.bool, device=device)
         self.partials = None
 
-    def step(self):
+    def step(self, marks=None):
+        """One pass over the batch.  `marks`: optional list that receives (stage name, torch.cuda.Event) pairs recorded on
+        the launch stream (= torch's current stream, which the library launches on) at every stage boundary."""
+        def mark(name):
+            if marks is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                marks.append((name, ev))
         cs = self.chunk
         pred = self.pred_lm.view(-1, 21, 3)
         gt = self.gt_lm.view(-1, 21, 3)
+        mark("start")
         for s0 in range(0, self.S, cs):
             s1, c0, c1 = s0 + cs, 2 * s0, 2 * (s0 + cs)
             if self.host_crop_cameras:          # crop cameras precomputed on the host at set-up
@@ -140,74 +149,152 @@ class Pipeline:
                 cams = gpu_crop.gen_crop_cameras_batched(pts, self.rig_cams, self.rig_angles, self.hand_idx[s0:s1],
                                                          forced_views=self.views[s0:s1])
                 dst, K, E = cams.dst_cams.view(-1, 20), cams.intrinsics.view(-1, 3, 3), cams.extrinsics.view(-1, 4, 4)
+            mark("crop_cameras")
             gpu_warp.warp_crops(self.images, self.src_off[c0:c1], self.src_pitch[c0:c1], self.src_cams[c0:c1],
                                 dst, out=self.crops)
+            mark("warp")
             fd = InputFrameData(self.crops, K, E)
             desc = InputFrameDesc(self.sample_range, self.memory_idx, self.use_memory, self.hand_idx[s0:s1])
             out = self.model.regress_pose_use_skeleton(fd, desc, self.skel, required_rows=cs)
+            mark("model")
             skin_landmarks(self.hm, out.joint_angles, out.wrist_xfs, hand_idx=self.hand_idx[s0:s1], mirror_right=True,
                            wrist_translation_scale=1000.0, out=pred[s0:s1])
             skin_landmarks(self.hm, self.gt_angles[s0:s1], self.gt_wrist[s0:s1], hand_idx=self.hand_idx[s0:s1],
                            mirror_right=True, out=gt[s0:s1])
+            mark("fk")
         self.partials = mu.metric_partials(self.gt_lm, self.pred_lm, self.valid)
+        mark("metric_partials")
         udist.all_reduce_partials(self.partials)
         return self.partials
 
 
-def cpu_baseline(pipe, n_hands, budget_s=12.0):
-    """Time the CPU oracle (port of the reference path, pinned to its goldens) on the first
-    `n_hands` samples of the same workload: warp + network + FK + metrics, all host cores torch uses."""
-    from types import SimpleNamespace
-    from oracle import fk as ofk, geometry as og, metrics as omx, model as om
-    wl = pipe.wl
-    n = min(n_hands, pipe.chunk)
-    imgs = pipe.images.cpu().numpy()
-    hm = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in pipe.hm._asdict().items() if v is not None}
-    state = arch.make_synthetic_state(0)
-    frame_bytes = synthetic.SRC_H * synthetic.SRC_W * synthetic.N_VIEWS
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    sd = om.to_torch_state(state)
+class CpuOracle:
+    """The CPU oracle (oracle/: a port of the reference path, pinned to its goldens) on samples of the same workload.
+    Test infrastructure used as the reported CPU baseline and as the parity checker; never part of the product path."""
 
-    def one_pass():
+    def __init__(self, pipe):
+        from oracle import fk as ofk, geometry as og, metrics as omx, model as om
+        self.ofk, self.og, self.om = ofk, og, om
+        self.pipe, self.wl = pipe, pipe.wl
+        self.imgs = pipe.images.cpu().numpy()
+        self.hm = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in pipe.hm._asdict().items() if v is not None}
+        self.frame_bytes = synthetic.SRC_H * synthetic.SRC_W * synthetic.N_VIEWS
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        self.sd = om.to_torch_state(arch.make_synthetic_state(0))
+        self.skel = SimpleNamespace(joint_rotation_axes=torch.from_numpy(self.hm["joint_rotation_axes"]).float(),
+                                    joint_rest_positions=torch.from_numpy(self.hm["joint_rest_positions"]).float() * 0.001)
+
+    def warp(self, h0, n):
+        """Crops of hands [h0, h0+n): fisheye -> pinhole, cv2 fixed-point sampling, /255 (tracker.py:54-80, 210-211)."""
+        wl, og = self.wl, self.og
         crops = np.empty((2 * n, 96, 96), np.float32)
-        for k in range(2 * n):
+        for i, k in enumerate(range(2 * h0, 2 * (h0 + n))):
             sc, dc = wl.src_cams[k], wl.dst_cams[k]
-            frame = imgs[(wl.src_offset[k] // frame_bytes) * frame_bytes:][:frame_bytes].reshape(synthetic.SRC_H, -1)
-            view = frame[:, (wl.src_offset[k] % frame_bytes):][:, :synthetic.SRC_W]
+            frame = self.imgs[(wl.src_offset[k] // self.frame_bytes) * self.frame_bytes:][:self.frame_bytes].reshape(synthetic.SRC_H, -1)
+            view = frame[:, (wl.src_offset[k] % self.frame_bytes):][:, :synthetic.SRC_W]
             src = og.Fisheye62(int(sc[0]), int(sc[1]), (sc[2], sc[3]), (sc[4], sc[5]), list(sc[6:14]), sc[14:].reshape(4, 4))
             dst = og.Pinhole(96, 96, (dc[0], dc[1]), (dc[2], dc[3]), dc[4:].reshape(4, 4))
-            crops[k] = og.warp_crop(src, dst, np.ascontiguousarray(view))
-        m = om.OracleModel(sd)
-        fd = SimpleNamespace(left_images=torch.from_numpy(crops), intrinsics=torch.from_numpy(wl.intrinsics[:2 * n]),
-                             extrinsics_xf=torch.from_numpy(wl.extrinsics[:2 * n]))
+            crops[i] = og.warp_crop(src, dst, np.ascontiguousarray(view))
+        return crops
+
+    def model(self, crops, h0, n):
+        """One regress_pose_use_skeleton call on n hands, a fresh model like the reference's per-recording one."""
+        wl = self.wl
+        m = self.om.OracleModel(self.sd)
+        fd = SimpleNamespace(left_images=torch.from_numpy(crops), intrinsics=torch.from_numpy(wl.intrinsics[2 * h0:2 * (h0 + n)]),
+                             extrinsics_xf=torch.from_numpy(wl.extrinsics[2 * h0:2 * (h0 + n)]))
         desc = SimpleNamespace(sample_range=torch.arange(n)[:, None] * 2 + torch.tensor([0, 2]),
                                memory_idx=torch.arange(n), use_memory=torch.zeros(n, dtype=torch.bool),
-                               hand_idx=torch.from_numpy(wl.hand_idx[:n]))
-        skel = SimpleNamespace(joint_rotation_axes=torch.from_numpy(hm["joint_rotation_axes"]).float(),
-                               joint_rest_positions=torch.from_numpy(hm["joint_rest_positions"]).float() * 0.001)
+                               hand_idx=torch.from_numpy(wl.hand_idx[h0:h0 + n]))
         with torch.no_grad():
-            out = m.regress_pose_use_skeleton(fd, desc, skel)
+            return m.regress_pose_use_skeleton(fd, desc, self.skel)
+
+    def landmarks(self, out, h0, n):
+        wl = self.wl
+        hidx = wl.hand_idx[h0:h0 + n]
         wx = out["wrist_xfs"].numpy().astype(np.float64)
         wx[:, :3, 3] *= 1000.0
-        wx[wl.hand_idx[:n] == 1, :, 0] *= -1
-        gtw = wl.wrist[:n].astype(np.float64).copy()
-        gtw[wl.hand_idx[:n] == 1, :, 0] *= -1
-        pred = ofk.skin_landmarks(hm, out["joint_angles"].numpy(), wx)
-        gt = ofk.skin_landmarks(hm, wl.joint_angles[:n], gtw)
+        wx[hidx == 1, :, 0] *= -1
+        gtw = wl.wrist[h0:h0 + n].astype(np.float64).copy()
+        gtw[hidx == 1, :, 0] *= -1
+        pred = self.ofk.skin_landmarks(self.hm, out["joint_angles"].numpy(), wx)
+        gt = self.ofk.skin_landmarks(self.hm, wl.joint_angles[h0:h0 + n], gtw)
         err = np.linalg.norm(gt.astype(np.float64) - pred.astype(np.float64), axis=-1).mean(-1)
         return pred, float(err.mean())
 
-    t0 = time.perf_counter()
-    pred, mpjpe = one_pass()
-    passes = 1
-    first = time.perf_counter() - t0
-    while time.perf_counter() - t0 + first < budget_s:
-        one_pass()
-        passes += 1
-    dt = (time.perf_counter() - t0) / passes
-    return {"value": n / dt, "unit": "hand-frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"first {n} hand-frames ({2 * n} crops) of the same workload, {passes} pass(es), "
-                      f"oracle warp(cv2 fixed-point)+network fp32+FK, {dt:.2f} s/pass"}, pred, mpjpe
+    def end_to_end(self, h0, n):
+        return self.landmarks(self.model(self.warp(h0, n), h0, n), h0, n)
+
+
+def cpu_baseline(pipe, n_hands, budget_s=12.0):
+    """the CPU oracle timed model-only and end-to-end (warp + network + FK + error) at batch 2
+    (the reference's per-frame call: one frame, two hands) and at batch `n_hands` (256), on the first hands of the
+    same workload, all host cores torch uses.  The headline entry is end-to-end at the large batch.  Returns
+    (cpu_baseline dict, oracle landmarks of the first n hands, their MPJPE)."""
+    cpu = CpuOracle(pipe)
+    n = min(n_hands, pipe.chunk)
+    share = budget_s / 4.0
+
+    def timed(fn, units, min_reps=1):
+        t0 = time.perf_counter()
+        reps, res = 0, None
+        while reps < min_reps or (time.perf_counter() - t0) * (reps + 1) / max(reps, 1) < share:
+            res = fn(reps)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+        return units / dt, dt, reps, res
+
+    e2e_v, e2e_dt, e2e_reps, (pred, mpjpe) = timed(lambda r: cpu.end_to_end(0, n), n)
+    crops = cpu.warp(0, n)
+    mod_v, mod_dt, mod_reps, _ = timed(lambda r: cpu.model(crops, 0, n), n)
+    nf = max(n // 2, 1)                                    # frames available for the per-frame configuration
+    e2e2_v, e2e2_dt, e2e2_reps, _ = timed(lambda r: cpu.end_to_end(2 * (r % nf), 2), 2, min_reps=2)
+    mod2_v, mod2_dt, mod2_reps, _ = timed(lambda r: cpu.model(crops[4 * (r % nf):4 * (r % nf) + 4], 2 * (r % nf), 2), 2, min_reps=2)
+    cores = torch.get_num_threads()
+    row = lambda v, dt, reps, what: {"value": v, "unit": "hand-frames/s", "s_per_call": dt, "calls": reps, "what": what}  # noqa: E731
+    return {"value": e2e_v, "unit": "hand-frames/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} hand-frames ({2 * n} crops) of the same workload in one call, {e2e_reps} pass(es), "
+                      f"oracle warp(cv2 fixed-point)+network fp32+FK, {e2e_dt:.2f} s/pass",
+            "matrix": {f"end_to_end_batch{n}": row(e2e_v, e2e_dt, e2e_reps, "warp + network + FK + error, one call"),
+                       f"model_only_batch{n}": row(mod_v, mod_dt, mod_reps, "network only (crops precomputed), one call"),
+                       "end_to_end_batch2": row(e2e2_v, e2e2_dt, e2e2_reps, "the reference's per-frame call: 1 frame = 2 hands = 4 crops"),
+                       "model_only_batch2": row(mod2_v, mod2_dt, mod2_reps, "network only, 2 hands per call"),
+                       "note": "SURVEY.md section 8(d) matrix; every cell is the oracle port on the GPU box's host cores "
+                               f"({cores} torch threads), bounded to about {budget_s:.0f} s in all"}}, pred, mpjpe
+
+
+def stage_rows(stage_ms, pipe, backbone_ms, forward_ms, mfma_peak):
+    """every stage of one step with its algorithmic bytes or FLOP, its HIP-event time and the
+    fraction of the roofline that bounds it.  Times other than the head's are from one extra step after the timed
+    region with an event at every stage boundary; the head is forward - backbone from the library's events inside
+    the timed region."""
+    S, n_crops = pipe.S, 2 * pipe.S
+    rows = []
+
+    def hbm(name, key, nbytes, per_unit):
+        ms = stage_ms.get(key)
+        if ms:
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            rows.append({"stage": name, "bound": "hbm", "ms": ms, "algorithmic_bytes": nbytes, "per_unit": per_unit,
+                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+
+    if not pipe.host_crop_cameras:
+        hbm("crop cameras (FK of 3 poses + look-at + K/E packing)", "crop_cameras", S * (3 * 404 + 756 + 2 * 260),
+            "3 x 404 B FK + 756 B in + 2 x 260 B out per hand; latency-bound fp64 4x4 algebra, HBM priced for completeness")
+    hbm("warp (fisheye -> pinhole crops)", "warp", n_crops * 73728, "73 728 B per crop (9216 px x (4 B written + 4 x 1 B gathered))")
+    head_ms = forward_ms - backbone_ms
+    head_flop = (2.05e6 + 1.75e6 + 15.31e6) * S
+    rows.append({"stage": "backbone (stem + 24 convolution launches)", "bound": "mfma", "ms": backbone_ms,
+                 "algorithmic_flop": BACKBONE_FLOP_PER_CROP * n_crops, "per_unit": "969.23 MFLOP per crop",
+                 "achieved": BACKBONE_FLOP_PER_CROP * n_crops / (backbone_ms * 1e-3) / 1e12, "peak": mfma_peak,
+                 "unit": "TFLOP/s", "frac": BACKBONE_FLOP_PER_CROP * n_crops / (backbone_ms * 1e-3) / 1e12 / mfma_peak})
+    rows.append({"stage": "head (fusion + temporal + regressor + decode)", "bound": "mfma", "ms": head_ms,
+                 "algorithmic_flop": head_flop, "per_unit": "2.05 + 1.75 + 15.31 MFLOP per hand-frame",
+                 "achieved": head_flop / (head_ms * 1e-3) / 1e12, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": head_flop / (head_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TFLOPS})
+    hbm("FK (prediction + ground truth)", "fk", 2 * S * 404, "404 B per hand-frame (shared hand model), two launches")
+    hbm("metric partials", "metric_partials", S * 504, "504 B per hand-frame")
+    return rows
 
 
 def stream_main(args, rank, world, dev):
@@ -245,12 +332,13 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU (weak scaling)")
     ap.add_argument("--frames-per-recording", type=int, default=64)
     ap.add_argument("--chunk-frames", type=int, default=4096)
-    ap.add_argument("--cpu-hands", type=int, default=128, help="hand-frames in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-hands", type=int, default=256,
+                    help="hand-frames in the large-batch cells of the CPU-baseline matrix (0 = skip the baseline)")
     ap.add_argument("--precision", choices=("fp32", "bf16", "fp32x3"), default="fp32",
                     help="backbone arithmetic; fp32 (fp32 matrix instructions, an fmaf chain per output) is the reference's and the "
                          "headline line; bf16 is a separate reduced-precision mode; fp32x3 keeps fp32 tensors and multiplies "
                          "three-way bf16 splits of the operands on the bf16 matrix pipe (fp32-level accuracy, reported separately)")
-    ap.add_argument("--no-x3", action="store_true", help="skip the fp32x3 side measurement of the default fp32 run")
+    ap.add_argument("--no-x3", action="store_true", help="skip the fp32x3 and bf16 side measurements of the default fp32 run")
     ap.add_argument("--host-crop-cameras", action="store_true",
                     help="use crop cameras precomputed on the host instead of generating them on the GPU each step")
     ap.add_argument("--stream-frames", type=int, default=0,
@@ -294,12 +382,10 @@ def main():
     fin = mu.finalize_partials(pipe.partials)
     parity_pred = pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy()   # throughput-mode landmarks
 
-    # side measurement (rank 0's GPU only, no collective in it): the same step with the stride-1 3x3 backbone layers on
-    # the bf16 matrix pipe through three-way operand splitting.  fp32 tensors, fp32-level accuracy; never `value`.
-    x3 = None
-    if args.precision == "fp32" and not args.no_x3 and world == 1:
-        pred32 = pipe.pred_lm.clone()
-        pipe.model.precision = "fp32x3"
+    # side measurements (rank 0's GPU only, no collective in them; never `value`): the same step in the two other
+    # backbone modes, 1 warm-up + 2 timed steps each, backbone time from the library's HIP events
+    def side_mode(precision, peak, note):
+        pipe.model.precision = precision
         pipe.step()
         torch.cuda.synchronize()
         pipe.model.timing_enable(True)
@@ -307,17 +393,28 @@ def main():
         for _ in range(2):
             pipe.step()
         torch.cuda.synchronize()
-        x3_dt = (time.perf_counter() - tx) / 2
-        x3_bb_ms, _, x3_calls = pipe.model.timing_read()
+        dt = (time.perf_counter() - tx) / 2
+        bb, fwd, ncalls = pipe.model.timing_read()
         pipe.model.timing_enable(False)
-        pipe.model.precision = "fp32"
-        x3_pred = pipe.pred_lm.view(-1, 21, 3)
-        x3 = {"value": pipe.S / x3_dt, "unit": "hand-frames/s", "ms_per_step": x3_dt * 1e3,
-              "backbone_tflops": BACKBONE_FLOP_PER_CROP * 2 * pipe.chunk / (x3_bb_ms / x3_calls * 1e-3) / 1e12,
-              "max_landmark_diff_vs_fp32_mm": float((pipe.pred_lm - pred32).abs().max()),
-              "x3_pred": x3_pred[:max(args.cpu_hands, 1)].cpu().numpy(),
-              "note": "UMT_PREC_FP32_BF16X3: fp32 tensors; each fp32 operand of the stride-1 3x3 backbone layers is the exact "
-                      "sum of three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulation; 2 timed steps"}
+        pipe.model.precision = args.precision
+        tf = BACKBONE_FLOP_PER_CROP * 2 * pipe.chunk / (bb / ncalls * 1e-3) / 1e12
+        return {"value": pipe.S / dt, "unit": "hand-frames/s", "ms_per_step": dt * 1e3, "backbone_ms": bb / ncalls,
+                "forward_ms": fwd / ncalls, "backbone_tflops": tf, "peak_tflops": peak, "frac": tf / peak,
+                "max_landmark_diff_vs_fp32_mm": float((pipe.pred_lm - pred32).abs().max()),
+                "mean_landmark_diff_vs_fp32_mm": float((pipe.pred_lm - pred32).abs().mean()),
+                "pred": pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy(), "note": note}
+
+    x3 = bf16_side = None
+    if args.precision == "fp32" and not args.no_x3 and world == 1:
+        pred32 = pipe.pred_lm.clone()
+        x3 = side_mode("fp32x3", BF16_MATRIX_PEAK_TFLOPS / 6,
+                       "UMT_PREC_FP32_BF16X3: fp32 tensors; each fp32 operand of the stride-1 3x3 backbone layers is the exact "
+                       "sum of three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product, fp32 accumulation; peak = bf16 "
+                       "dense peak / 6; 2 timed steps")
+        bf16_side = side_mode("bf16", BF16_MATRIX_PEAK_TFLOPS,
+                              "UMT_PREC_BF16: bf16 backbone activations and weights, fp32 accumulation; fusion, temporal memory, "
+                              "head and FK stay fp32; peak = bf16 dense matrix peak; 2 timed steps; stated tolerance vs the "
+                              "fp32 mode 1.5 mm per landmark (tests/test_gpu_bf16.py)")
 
     # per-launch view of the backbone (outside the timed region: the library records a HIP event between every two
     # launches, which costs a little): one more step in the headline precision
@@ -325,6 +422,14 @@ def main():
     pipe.step()
     layer_rows = pipe.model.layer_timing_read()
     pipe.model.layer_timing_enable(False)
+
+    # per-stage view (section 8d): one more step with a HIP event on the launch stream at every stage boundary
+    marks = []
+    pipe.step(marks)
+    torch.cuda.synchronize()
+    stage_ms = {}
+    for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
+        stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1)
 
     # second mode of section 8(d): the same batch as 64-frame recordings in lock-step with the temporal
     # memory ON (bulk backbone, then T sequential memory+regressor steps); per-rank, no collective
@@ -409,6 +514,7 @@ def main():
                                          "note": "HIP events recorded by the library between the launches of one extra step after "
                                                  "the timed region; stride-1 3x3 layers with 128 and 256 channels"},
                      "layers": [{"launch": r[0], "ms": r[2] / max(r[3], 1), "tflops": r[1] / max(r[2], 1e-9) / 1e9} for r in layer_rows]},
+        "stages": stage_rows(stage_ms, pipe, bb_ms / calls, fwd_ms / calls, peak),
         "model_tflops": MODEL_FLOP_PER_HAND * pipe.S * args.steps / elapsed / 1e12,
         "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa,
         "recurrent": {"value_per_gpu": pipe.S / rec_dt, "unit": "hand-frames/s", "ms_per_step": rec_dt * 1e3,
@@ -456,11 +562,13 @@ def main():
         line["cpu_baseline"] = base
         n = cpu_pred.shape[0]
         line["parity_sample_max_mm"] = float(np.abs(parity_pred[:n] - cpu_pred).max())
-        if x3 is not None:
-            x3["parity_sample_max_mm"] = float(np.abs(x3["x3_pred"][:n] - cpu_pred).max())
-    if x3 is not None:
-        x3.pop("x3_pred")
-        line["fp32_bf16x3"] = x3
+        for side in (x3, bf16_side):
+            if side is not None:
+                side["parity_sample_max_mm"] = float(np.abs(side["pred"][:n] - cpu_pred).max())
+    for key, side in (("fp32_bf16x3", x3), ("bf16", bf16_side)):
+        if side is not None:
+            side.pop("pred")
+            line[key] = side
     print(json.dumps(line))
 
 

@@ -237,6 +237,16 @@ int main(int argc, char** argv) {
       const double bytes = (double)(in_n / (sh.stride * sh.stride) + out_n * (1 + sh.res)) * esz;
       printf("%s cin %3d cout %3d hw %2d taps %d s%d res %d : %8.1f us  %6.1f TF  %5.2f TB/s\n", bf ? "bf16" : "f32 ", sh.cin,
              sh.cout, sh.hw, sh.taps, sh.stride, sh.res, ms * 1e3, fl / ms / 1e9, bytes / ms / 1e9);
+#ifdef UMT_STAMP
+      {
+        unsigned long long h[2][64][4];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
+        for (int ph = 0; ph < 22; ++ph)
+          printf("  ph %2d  g0: start %8llu work %7llu (epi %7llu)   g1: start %8llu work %7llu (epi %7llu)\n", ph,
+                 h[0][ph][0] - h[0][0][0], h[0][ph][1] - h[0][ph][0], h[0][ph][2] > h[0][ph][0] ? h[0][ph][2] - h[0][ph][0] : 0,
+                 h[1][ph][0] - h[0][0][0], h[1][ph][1] - h[1][ph][0], h[1][ph][2] > h[1][ph][0] ? h[1][ph][2] - h[1][ph][0] : 0);
+      }
+#endif
       hipFree(in); hipFree(out); hipFree(res); hipFree(w); hipFree(vec);
     }
   }

@@ -45,6 +45,13 @@ struct ThinArgs {
   int ntiles;
   unsigned mg_hw, mg_w;  // floor(2^32 / (H*W)) + 1 and floor(2^32 / W) + 1
 };
+#ifdef UMT_STAMP
+// diagnostic build only (tools/conv_bench.hip): cycle stamps of workgroup 0, never part of the library
+__device__ unsigned long long g_stamp[2][64][4];
+#define STAMP(ph, k) do { if (blockIdx.x == 0 && tid == 0 && (ph) < 64) g_stamp[group][ph][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(ph, k) do {} while (0)
+#endif
 
 __device__ __forceinline__ int thin_div(int m, int d, unsigned mg) {      // floor(m / d), 0 <= m < 2^31
   int q = (int)__umulhi((unsigned)m, mg);
@@ -527,6 +534,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
   f32x16 acc[2][2];
   uint4 res[2][2][2];
   for (int ph = 0; ph < nphase; ++ph) {
+    STAMP(ph, 0);
     const int j = (ph - group) >> 1;
     const bool mfma_phase = ((ph - group) & 1) == 0;
     if (ph >= group && j < gw.count) {
@@ -549,6 +557,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
           for (int n = 0; n < 2; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
+        // A fragments run one k-step ahead of their MFMAs: in an MFMA phase this wave is the only one on its SIMD that
+        // issues matrix instructions (its partner is in the epilogue), so a read waited for in its own k-step leaves
+        // the pipe idle for the whole LDS latency (measured: 236 cycles per k-step against 128 of MFMA)
+        uint4 av[2][2];
+        auto read_a = [&](uint4 (&dst)[2], int ks) {
+          const int tap = (ks % 18) >> 1, c16 = (ks / 18) * 2 + (ks & 1);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const uint4*>(sA + arow[i][tap] + c16 * 32);
+        };
+        read_a(av[0], 0);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
           if (ks + R - 1 < NK) load_bk(bk[(ks + R - 1) % R], ks + R - 1);
@@ -567,16 +585,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
                   }
             }
           }
+          if (ks + 1 < NK) read_a(av[(ks + 1) & 1], ks + 1);
           __builtin_amdgcn_sched_barrier(0);
-          const int chunk = ks / 18, tap = (ks % 18) >> 1, c16 = chunk * 2 + (ks & 1);
-          uint4 av[2];
-#pragma unroll
-          for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const uint4*>(sA + arow[i][tap] + c16 * 32);
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
-              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i]),
+              acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ks & 1][i]),
                                                                   __builtin_bit_cast(bf16x8, bk[ks % R][n]), acc[i][n], 0, 0, 0);
         }
       } else {
@@ -620,9 +635,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
             __builtin_amdgcn_wave_barrier();
           }
         }
+        STAMP(ph, 2);
         if (j + 1 < gw.count) write_a();
       }
     }
+    STAMP(ph, 1);
     __syncthreads();
   }
 }
