@@ -186,6 +186,22 @@ int umt_model_forward(umt_model* m, int head, int precision, const float* images
                       float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- whole recordings in lock-step: the T sequential calls of SimpleConvRNN.forward_temporal_features +
+ * PoseRegressor.regress_poses that run_eval_known_skeleton.py:68-86 makes frame by frame (temporal.py:93-139,
+ * regressor.py:163-186, umetrack_model.py:77-90), for `rows` memory rows at once in ONE launch.  Sample r of step t
+ * uses memory row r (memory_idx = arange(rows) in every step); the caller has reserved >= rows rows.  The handle's
+ * state is read at the start and written back at the end, so the call composes with umt_temporal_step.
+ * Time-major inputs, all dev: fused_t f32 (t, rows, 72, 6, 6) = umt_fuse_views outputs; cam0_t f32 (t, rows, 4, 4);
+ * use_memory_t uint8 (t, rows); hand_idx int64 (t, rows); skeleton as umt_regress_decode.
+ * Outputs time-major: joint_angles_t (t, rows, 22), wrist_xfs_t (t, rows, 4, 4), sigmas_t (t, rows, 21),
+ * skel_scales_t (t, rows) (scale head).  Results are bit-identical to t calls of umt_temporal_step +
+ * umt_regress_decode.                                                                                     */
+int64_t umt_head_sequence_workspace_bytes(int t, int rows);
+int umt_head_sequence(umt_model* m, int head, const float* fused_t, const float* cam0_t, const uint8_t* use_memory_t,
+                      const int64_t* hand_idx, const float* skel_axes, const float* skel_rest, int n_skel, int t,
+                      int rows, float* joint_angles_t, float* wrist_xfs_t, float* sigmas_t, float* skel_scales_t,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- measurement aid, no counterpart in the reference: when enabled, umt_model_forward records
  * HIP events on the caller's stream before the backbone, after it and at the end of the call;
  * umt_model_timing_read waits for them and returns the summed durations since the last enable.

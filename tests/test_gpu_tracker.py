@@ -188,6 +188,16 @@ def test_bulk_runner_equals_frame_by_frame(hand_model_np):
     runner = bulk.BulkSequenceRunner(model, n_rec, T, chunk_samples=8)   # chunking that does not divide S
     runner.features(images, off, pit, sc, dc, K, E)
     got = runner.run(E, hidx, skel, valid)
+    # the one-launch sequence kernel (default) and the stepwise loop give the same bits, state included
+    mem_seq, prev_seq = model.memory_state()
+    step = runner.run(E, hidx, skel, valid, stepwise=True)
+    mem_step, prev_step = model.memory_state()
+    keep_all = valid.reshape(-1)
+    assert torch.equal(got.joint_angles[keep_all], step.joint_angles[keep_all])
+    assert torch.equal(got.wrist_xfs[keep_all], step.wrist_xfs[keep_all])
+    assert torch.equal(got.landmark_uncertainty_sigmas[keep_all], step.landmark_uncertainty_sigmas[keep_all])
+    assert torch.equal(mem_seq, mem_step) and torch.equal(prev_seq, prev_step)
+    model.check_status()
     # frame-by-frame on a second model instance + the oracle
     model2 = model_from_state_dict(state).to(dev)
     oracle = om.OracleModel(state)

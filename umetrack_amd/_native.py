@@ -57,6 +57,8 @@ SIGNATURES = {
     "umt_regress_decode": (c_int, [_P, c_int, _P, _P, _P, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "umt_model_forward": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int,
                                   _P, _P, _P, _P, _P, c_int64, _P]),
+    "umt_head_sequence_workspace_bytes": (c_int64, [c_int, c_int]),
+    "umt_head_sequence": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
     "umt_model_timing_enable": (c_int, [_P, c_int]),
     "umt_model_timing_read": (c_int, [_P, POINTER(c_double), POINTER(c_double), POINTER(c_int)]),
     "umt_model_layer_timing_enable": (c_int, [_P, c_int]),

@@ -60,7 +60,8 @@ class BulkSequenceRunner:
             self.fused_t[:, s0 // T:s1 // T] = fused.view(n // T, T, 72, 6, 6).transpose(0, 1)
         return self.fused_t
 
-    def run(self, E, hand_idx, skel: InputSkeletonData, valid: Optional[torch.Tensor] = None) -> RegressorOutput:
+    def run(self, E, hand_idx, skel: InputSkeletonData, valid: Optional[torch.Tensor] = None,
+            stepwise: bool = False) -> RegressorOutput:
         """Phase 2: T lock-step temporal + regressor steps.  ``valid`` [n_rec*2, T] marks tracked
         hand-frames; a hand uses its memory when it was tracked in the previous frame
         (tracker.py:233-236, 278-285).  Rows of untracked hand-frames are computed but meaningless."""
@@ -71,6 +72,14 @@ class BulkSequenceRunner:
         cam0_t = E[0::2].view(R, T, 4, 4).transpose(0, 1).contiguous()
         hand_rows = hand_idx.view(R, T)[:, 0].contiguous()
         valid_t = valid.t().contiguous() if valid is not None else torch.ones(T, R, dtype=torch.bool, device=dev)
+        if not stepwise:
+            # one launch for all T steps (csrc/head_seq.hip): a workgroup per memory row keeps the row's state and
+            # activations in LDS; bit-identical to the stepwise loop below, which stays as the check
+            use_t = torch.cat([torch.zeros(1, R, dtype=torch.bool, device=dev), valid_t[:-1]], 0).contiguous()
+            out = m.head_sequence(nat.HEAD_KNOWN_SKELETON, self.fused_t, cam0_t, use_t, hand_rows.repeat(T, 1), skel)
+            return RegressorOutput(out.joint_angles.transpose(0, 1).reshape(self.S, 22),
+                                   out.wrist_xfs.transpose(0, 1).reshape(self.S, 4, 4), None,
+                                   out.landmark_uncertainty_sigmas.transpose(0, 1).reshape(self.S, 21))
         ja_t = torch.empty(T, R, 22, device=dev)
         wx_t = torch.empty(T, R, 4, 4, device=dev)
         sg_t = torch.empty(T, R, 21, device=dev)

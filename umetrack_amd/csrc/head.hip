@@ -8,55 +8,11 @@
 // svd chains (lib/models/feature_extractor.py:61-87, temporal.py:51-78, model_utils.py:17-54,
 // umetrack_model.py:77-90).
 #include "umt_internal.h"
+#include "head_math.h"
 
 namespace umt {
 
 static inline unsigned grid_for(int64_t total, int block) { return (unsigned)((total + block - 1) / block); }
-
-// ---------------------------------------------------------------- small device linear algebra
-__device__ inline void mat4_mul(const double* a, const double* b, double* c) {
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      double s = 0;
-      for (int k = 0; k < 4; ++k) s += a[i * 4 + k] * b[k * 4 + j];
-      c[i * 4 + j] = s;
-    }
-}
-
-// Gauss-Jordan with partial pivoting; a singular input yields inf/nan where torch.inverse would raise.
-// Returns false when a pivot is exactly zero or not finite (the matrix is singular to working precision).
-__device__ inline bool mat4_inv(const double* m, double* inv) {
-  bool regular = true;
-  double a[4][8];
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) {
-      a[i][j] = m[i * 4 + j];
-      a[i][4 + j] = (i == j) ? 1.0 : 0.0;
-    }
-  for (int col = 0; col < 4; ++col) {
-    int piv = col;
-    double best = fabs(a[col][col]);
-    for (int r = col + 1; r < 4; ++r)
-      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
-    if (piv != col)
-      for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
-    if (!(fabs(a[col][col]) > 0.0) || !isfinite(a[col][col])) regular = false;
-    const double d = 1.0 / a[col][col];
-    for (int j = 0; j < 8; ++j) a[col][j] *= d;
-    for (int r = 0; r < 4; ++r)
-      if (r != col) {
-        const double f = a[r][col];
-        for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
-      }
-  }
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
-  return regular;
-}
-
-__device__ inline void load_mat4(const float* src, double* dst) {
-  for (int i = 0; i < 16; ++i) dst[i] = (double)src[i];
-}
 
 // ---------------------------------------------------------------- layout converters
 __global__ void rows_to_nchw_kernel(const float* rows, int cs, int c0, int c, int64_t total, int hw, float* nchw) {
@@ -173,11 +129,6 @@ int launch_fusion_xforms(const float* intrinsics, const float* extrinsics, const
 
 // FTL on channels-last rows: the reference reshapes (C,6,6) to (3, C/3*36), so channel c,
 // c+C/3, c+2C/3 of one pixel form one 3-D point (model_utils.py:89-99).
-__device__ inline void ftl_point(const float* xf, float x, float y, float z, float& ox, float& oy, float& oz) {
-  ox = xf[0] * x + xf[1] * y + xf[2] * z + xf[3];
-  oy = xf[4] * x + xf[5] * y + xf[6] * z + xf[7];
-  oz = xf[8] * x + xf[9] * y + xf[10] * z + xf[11];
-}
 
 // cat_rows [bs*36][144]: channels v*72.. of sample b = FTL(to_canon[r0+v]) of crop r0+v; zeros for 1-view samples
 __global__ void ftl_concat_kernel(const float* feat, const float* crop_xf, const int64_t* sr,

@@ -290,6 +290,36 @@ static void pack_conv_x3(const umt_model* m, std::vector<uint16_t>& host, std::v
   packed.push_back(p);
 }
 
+// fp32 weights for head_seq.hip (v_mfma_f32_16x16x4_f32): packed[kk][j][co][s] with kk walking (32-channel chunk,
+// tap, 16-channel half) and ci = 32 chunk + 16 half + 8 (s >> 1) + 2 (s & 1) + {0, 4, 1, 5}[j]: k slot j of MFMA s.
+// That is the order in which conv_igemm.hip's kernels accumulate, so both paths give the same bits.
+struct PackedSeq {
+  ConvLayer* layer;
+  size_t off;
+};
+static void pack_conv_seq(const umt_model* m, std::vector<float>& host, std::vector<PackedSeq>& packed, ConvLayer* L,
+                          const std::string& wkey) {
+  const std::vector<float>& w = val(m, wkey);
+  const int cin_p = round_up(L->cin, 16), cout_p = round_up(L->cout, 16);
+  static const int T4[4] = {0, 4, 1, 5};
+  PackedSeq p{L, host.size()};
+  host.resize(host.size() + (size_t)L->taps * (cin_p / 16) * 4 * cout_p * 4, 0.f);
+  float* dst = host.data() + p.off;
+  size_t kk = 0;
+  for (int chunk = 0; chunk * 32 < cin_p; ++chunk) {
+    const int ng = cin_p - 32 * chunk >= 32 ? 2 : 1;
+    for (int tap = 0; tap < L->taps; ++tap)
+      for (int g = 0; g < ng; ++g, ++kk)
+        for (int j = 0; j < 4; ++j)
+          for (int co = 0; co < L->cout; ++co)
+            for (int s = 0; s < 4; ++s) {
+              const int ci = 32 * chunk + 16 * g + 8 * (s >> 1) + 2 * (s & 1) + T4[j];
+              if (ci < L->cin) dst[((kk * 4 + j) * cout_p + co) * 4 + s] = w[((size_t)co * L->cin + ci) * L->taps + tap];
+            }
+  }
+  packed.push_back(p);
+}
+
 static void pack_block(const umt_model* m, std::vector<float>& host, std::vector<Packed>& packed, BlockLayers* B,
                        const std::string& p, int stride, bool down) {
   pack_conv(m, host, packed, &B->conv1, p + ".conv1.weight", "", p + ".bn1", stride, 1);
@@ -806,15 +836,23 @@ static int finalize_on_device(umt_model* m, int device) {
   pack_conv(m, host, packed, &m->fuse1, fu + ".0.weight", fu + ".0.bias", fu + ".1", 1, 1);
   pack_conv(m, host, packed, &m->fuse2, fu + ".3.weight", fu + ".3.bias", fu + ".4", 1, 1);
   pack_conv(m, host, packed, &m->fuse3, fu + ".6.weight", fu + ".6.bias", "", 1, 0);
+  std::vector<PackedSeq> packed_seq;
   for (int i = 0; i < 3; ++i) {
     const std::string p = "_temporal._temporal_module." + std::to_string(2 * i);
     pack_conv(m, host, packed, &m->temp[i], p + ".weight", p + ".bias", "", 1, i < 2 ? 1 : 0);
+    pack_conv_seq(m, host, packed_seq, &m->temp[i], p + ".weight");
   }
   const char* heads[2] = {"_regressor_k", "_regressor_u"};
   for (int h = 0; h < 2; ++h) {
     const std::string p = std::string(heads[h]) + "._pose_regression_layers";
-    for (int b = 0; b < 2; ++b) pack_block(m, host, packed, &m->reg_blocks[h][b], p + "." + std::to_string(b), 1, false);
+    for (int b = 0; b < 2; ++b) {
+      const std::string pb = p + "." + std::to_string(b);
+      pack_block(m, host, packed, &m->reg_blocks[h][b], pb, 1, false);
+      pack_conv_seq(m, host, packed_seq, &m->reg_blocks[h][b].conv1, pb + ".conv1.weight");
+      pack_conv_seq(m, host, packed_seq, &m->reg_blocks[h][b].conv2, pb + ".conv2.weight");
+    }
     pack_conv(m, host, packed, &m->reg_out[h], p + ".2.weight", p + ".2.bias", "", 1, 0);
+    pack_conv_seq(m, host, packed_seq, &m->reg_out[h], p + ".2.weight");
   }
   // skeleton encoder
   size_t sk_off[4];
@@ -852,6 +890,7 @@ static int finalize_on_device(umt_model* m, int device) {
   }
   UMT_CHECK_HIP(hipMalloc((void**)&m->slab_h, host_h.size() * sizeof(uint16_t)));
   UMT_CHECK_HIP(hipMemcpy(m->slab_h, host_h.data(), host_h.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  for (const PackedSeq& p : packed_seq) p.layer->w16 = m->slab + p.off;   // sizes are multiples of 4 floats: 16-B aligned
   for (const PackedH& p : packed_h) p.layer->wh = m->slab_h + p.off;   // every size is a multiple of 8 bf16 = 16 B
   for (const PackedH& p : packed_x3) p.layer->wx3 = m->slab_h + p.off;
   m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3]};
@@ -1084,6 +1123,43 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
   UMT_TRY(regress_rows(m, head, skel_axes, skel_rest, n_skel, hw.cam0, hand_idx, bs, hw, joint_angles, wrist_xfs, sigmas,
                        skel_scales, nullptr, s));
   if (ev) UMT_CHECK_HIP(hipEventRecord(ev[2], s));
+  return 0;
+}
+
+extern "C" int64_t umt_head_sequence_workspace_bytes(int t, int rows) {
+  return head_sequence_workspace_bytes(t > 0 ? t : 1, rows > 0 ? rows : 1);
+}
+
+extern "C" int umt_head_sequence(umt_model* m, int head, const float* fused_t, const float* cam0_t,
+                                 const uint8_t* use_memory_t, const int64_t* hand_idx, const float* skel_axes,
+                                 const float* skel_rest, int n_skel, int t, int rows, float* joint_angles_t,
+                                 float* wrist_xfs_t, float* sigmas_t, float* skel_scales_t, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(head == UMT_HEAD_KNOWN_SKELETON || head == UMT_HEAD_PREDICT_SCALE, UMT_ERR_INVALID, "head = %d", head);
+  UMT_REQUIRE(t > 0 && rows > 0 && (int64_t)t * rows < ((int64_t)1 << 24), UMT_ERR_INVALID, "head_sequence: t=%d rows=%d", t, rows);
+  UMT_REQUIRE(fused_t && cam0_t && use_memory_t && hand_idx && joint_angles_t && wrist_xfs_t && sigmas_t, UMT_ERR_INVALID,
+              "head_sequence: null pointer");
+  UMT_REQUIRE(rows <= m->mem_rows, UMT_ERR_STATE, "head_sequence: %d rows but %d memory rows reserved (umt_model_reserve_memory)",
+              rows, m->mem_rows);
+  const bool known = head == UMT_HEAD_KNOWN_SKELETON;
+  if (known) {
+    UMT_REQUIRE(skel_axes && skel_rest, UMT_ERR_INVALID, "known-skeleton head needs skeleton data");
+    UMT_REQUIRE(n_skel == 1 || n_skel == rows, UMT_ERR_INVALID, "n_skel must be 1 or rows (%d), got %d", rows, n_skel);
+  } else {
+    UMT_REQUIRE(skel_scales_t, UMT_ERR_INVALID, "scale head needs a skel_scales buffer");
+  }
+  UMT_TRY(check_ws("head_sequence", workspace, workspace_bytes, umt_head_sequence_workspace_bytes(t, rows)));
+  hipStream_t s = (hipStream_t)stream;
+  const BlockLayers* B = m->reg_blocks[head];
+  const ConvLayer convs[4] = {B[0].conv1, B[0].conv2, B[1].conv1, B[1].conv2};
+  const int nraw = known ? 62 : 63;
+  float* raw = nullptr;
+  UMT_TRY(launch_head_sequence(m->temp, convs, m->reg_out[head], known ? &m->skel : nullptr, skel_axes, skel_rest, n_skel,
+                               fused_t, cam0_t, use_memory_t, t, rows, nraw, m->mem, m->prev_ext, m->status, &raw, workspace, s));
+  // Procrustes decode + wrist recovery for all t x rows outputs at once (hand_idx is time-major like the outputs)
+  UMT_TRY(launch_decode(raw, nraw, !known, cam0_t, hand_idx, t * rows, joint_angles_t, wrist_xfs_t, sigmas_t, skel_scales_t,
+                        m->status, s));
   return 0;
 }
 

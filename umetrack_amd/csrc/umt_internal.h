@@ -102,6 +102,7 @@ struct ConvLayer {
   const float* shift = nullptr;  // dev [cout_w]
   const uint16_t* wh = nullptr;  // dev, bf16 packed [tap][cin_s/16][2][cout_w][8] (backbone layers only)
   const uint16_t* wx3 = nullptr; // dev, three-way bf16 split [tap][cin_s/16][plane][2][cout_w][8] (backbone 3x3 layers)
+  const float* w16 = nullptr;    // dev, packed for v_mfma_f32_16x16x4_f32 (head_seq.hip; temporal and regressor layers only)
   unsigned flags = 0;            // CONV_* kernel-selection switches of the owning model handle
 };
 
@@ -189,5 +190,14 @@ int launch_decode(const float* raw, int nraw, int predict_scale, const float* ca
                   float* sigmas, float* skel_scales, int32_t* status, hipStream_t s);
 int launch_gather_cam0(const float* extrinsics, const int64_t* sample_range, int n, int bs,
                        float* cam0, hipStream_t s);
+
+// head_seq.hip: temporal module + regressor layers + average pool for R memory rows x T steps in one launch.
+// temp: 3 temporal layers, convs: conv1, conv2 of the two regressor blocks, out: the 1x1 output layer; skel null for the
+// scale head.  *raw_t receives the (T, R, nraw) regressor outputs inside `workspace`.
+int64_t head_sequence_workspace_bytes(int T, int R);
+int launch_head_sequence(const ConvLayer* temp, const ConvLayer* convs, const ConvLayer& out, const SkelParams* skel,
+                         const float* skel_axes, const float* skel_rest, int n_skel, const float* fused_t,
+                         const float* cam0_t, const uint8_t* use_t, int T, int R, int nraw, float* mem, float* prev_ext,
+                         int32_t* status, float** raw_t, void* workspace, hipStream_t s);
 
 }  // namespace umt

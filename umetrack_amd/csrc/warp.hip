@@ -251,7 +251,14 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
         if ((i & 3) == 0) { gv = p / out_w; gu = p - gv * out_w; }      // one division per group of 4 pixels
         int u = gu + (i & 3), v = gv;
         if (u >= out_w) { u -= out_w; ++v; }
+#ifdef UMT_WARP_X_NOMAP
+        sxs[i] = (int)(f.cx * 32.f) + 20 * u + 3 * v; sys[i] = (int)(f.cy * 32.f) + 21 * v - 2 * u;
+#else
         undecided = !map_point_fast(f, u, v, sxs[i], sys[i]);
+#endif
+#ifdef UMT_WARP_X_NOQUEUE
+        if (undecided) { undecided = false; sxs[i] = sys[i] = 64; }
+#endif
       }
       if (undecided) {
         const int pos = atomicAdd(&qcount, 1);
@@ -354,6 +361,12 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
   const bool use_lds = !empty && (int64_t)tpitch * th <= WARP_LDS_BYTES;   // uniform over the workgroup
 
   float res[WARP_MAX_PX];
+#ifdef UMT_WARP_X_NOGATHER
+  if (use_lds || !use_lds) {
+#pragma unroll
+    for (int i = 0; i < WARP_MAX_PX; ++i) res[i] = (float)(sxs[i] + sys[i] + bx0 + by1);
+  } else
+#endif
   if (use_lds) {
     // aligned 4-byte copies: LDS row r holds the dwords that cover source bytes [bx0, bx0 + tw) of row by0 + r
     const int tpd = tpitch >> 2;

@@ -297,6 +297,40 @@ class UmeTrackModel:
                                           nat.ptr(out), nat.ptr(ws), ws.numel(), st), "umt_temporal_step")
         return out
 
+    def head_sequence(self, head: int, fused_t, cam0_t, use_memory_t, hand_idx_t, skel: Optional[InputSkeletonData] = None
+                      ) -> RegressorOutput:
+        """T lock-step calls of temporal_step + regress_decode in ONE launch (umt_head_sequence): fused_t
+        [T,R,72,6,6], cam0_t [T,R,4,4], use_memory_t [T,R] bool, hand_idx_t [T,R]; row r of every step uses memory row
+        r.  Returns time-major outputs [T,R,...]; bit-identical to the stepwise calls."""
+        dev, L = self._device, nat.lib()
+        f32 = torch.float32
+        f = nat.dev_tensor(fused_t, f32, dev)
+        T, R = int(f.shape[0]), int(f.shape[1])
+        E0 = nat.dev_tensor(cam0_t, f32, dev)
+        use = nat.dev_tensor(use_memory_t, torch.bool, dev).view(torch.uint8)
+        hidx = nat.dev_tensor(hand_idx_t, torch.int64, dev)
+        assert tuple(f.shape) == (T, R, 72, 6, 6) and tuple(E0.shape) == (T, R, 4, 4) and use.numel() == T * R \
+            and hidx.numel() == T * R
+        axes = rest = None
+        n_skel = 0
+        if head == nat.HEAD_KNOWN_SKELETON:
+            axes = nat.dev_tensor(skel.joint_rotation_axes, f32, dev).reshape(-1, 22, 3)
+            rest = nat.dev_tensor(skel.joint_rest_positions, f32, dev).reshape(-1, 22, 3)
+            n_skel = axes.shape[0]
+        out = RegressorOutput(torch.empty(T, R, 22, dtype=f32, device=dev), torch.empty(T, R, 4, 4, dtype=f32, device=dev),
+                              torch.empty(T, R, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
+                              torch.empty(T, R, 21, dtype=f32, device=dev))
+        nbytes = L.umt_head_sequence_workspace_bytes(T, R)
+        ws = self._ws.get(dev, nbytes)
+        with torch.cuda.device(dev):
+            st = nat.stream_ptr(dev)
+            nat.check(L.umt_model_reserve_memory(self._h, R, st), "umt_model_reserve_memory")
+            nat.check(L.umt_head_sequence(self._h, head, nat.ptr(f), nat.ptr(E0), nat.ptr(use), nat.ptr(hidx), nat.ptr(axes),
+                                          nat.ptr(rest), n_skel, T, R, nat.ptr(out.joint_angles), nat.ptr(out.wrist_xfs),
+                                          nat.ptr(out.landmark_uncertainty_sigmas), nat.ptr(out.skel_scales), nat.ptr(ws),
+                                          ws.numel(), st), "umt_head_sequence")
+        return out
+
     def regress_decode(self, head: int, temporal, cam0_extrinsics, hand_idx, skel: Optional[InputSkeletonData] = None,
                        out: Optional[RegressorOutput] = None, want_raw: bool = True):
         """Skeleton encoder + PoseRegressor.regress_poses + wrist recovery; returns (RegressorOutput, raw).
