@@ -55,60 +55,71 @@ __device__ __forceinline__ int sq_pos(int c) {
 }
 
 // One convolution (1x1 or 3x3 on the 6x6 map) from LDS rows `in` to LDS rows `out`: 16 x 16 output tiles dealt to the
-// 16 waves, (pixel tile fastest).  Bit-identical to launch_conv on the same data (see the file header).
+// 16 waves (pixel tile fastest).  Bit-identical to launch_conv on the same data (see the file header).
+// Per k group (16 input channels of one tap) a wave issues one ds_read_b128 (activations, one group ahead), one 16-byte
+// buffer load (weights, four groups ahead in a ring of four register sets with static indices, scalar offset) and four
+// dependent MFMAs; the address arithmetic is a bit-field extract from the lane's packed table of operand rows plus
+// a few scalar instructions (16 waves share the CU's scalar unit: a first version with ~45 scalar instructions per
+// group ran at 40 % of the matrix pipe's rate).
+// k group kk of a layer with TAPS taps and CINP (padded) input channels: walk order 32-channel chunk, tap, 16-channel
+// half of the chunk.  Everything about a group is a compile-time constant of the fully unrolled loop.
+template <int TAPS, int CINP>
+struct SqWalk {
+  static constexpr int NKK = TAPS * (CINP / 16);
+  static constexpr int NKK4 = (NKK + 3) & ~3;
+  static constexpr int full = (CINP / 32) * TAPS * 2;      // groups in the full 32-channel chunks
+  static constexpr int chunk(int kk) { return kk < full ? kk / (2 * TAPS) : CINP / 32; }
+  static constexpr int tap(int kk) { return kk >= NKK ? 9 : kk < full ? (kk % (2 * TAPS)) / 2 : kk - full; }
+  static constexpr int col(int kk) { return kk >= NKK ? 0 : kk < full ? 32 * chunk(kk) + 16 * (kk & 1) : 32 * (CINP / 32); }
+};
+
+template <int TAPS, int CINP>
 __device__ __forceinline__ void sq_conv(const SeqLayer& L, const float* __restrict__ in, float* __restrict__ out,
                                         const float* __restrict__ res, int wave, int lane) {
+  typedef SqWalk<TAPS, CINP> Wk;
   const int r = lane & 15, j = lane >> 4;
   const int n_nt = L.cout_p >> 4, ntiles = 3 * n_nt;
-  const int nkk = L.taps * (L.cin_p >> 4);
-  const size_t kstride = (size_t)16 * L.cout_p;         // floats between two k groups of the packed weights
+  const int kbytes = 16 * L.cout_p * 4;                 // bytes between two k groups of the packed weights
+  const __amdgpu_buffer_rsrc_t wrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.w16), 0, (Wk::NKK4 + 4) * kbytes, 0x00020000);
   for (int tile = wave; tile < ntiles; tile += SQ_WAVES) {
     const int mt = tile % 3, nt = tile / 3;
     const int px = mt * 16 + r;
     const int py = px / 6, pxx = px - py * 6;
-    const float* wp = L.w16 + ((size_t)j * L.cout_p + nt * 16 + r) * 4;
-    // walk of the k groups: 32-channel chunk, tap, 16-channel half of the chunk
-    int chunk = 0, tap = 0, g = 0;
-    auto a_ptr = [&]() -> const float* {
-      int row = px;
-      bool ok = px < 36;
-      if (L.taps == 9) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int yy = py + ky - 1, xx = pxx + kx - 1;
-        ok = ok && (unsigned)yy < 6u && (unsigned)xx < 6u;
-        row = yy * 6 + xx;
+    // float index of the lane's operand row per tap (row 36 = the all-zero row); entry 9 serves the padding groups
+    int rowoff[10];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      int row = SQ_ZERO;
+      if (TAPS == 9) {
+        const int yy = py + tap / 3 - 1, xx = pxx + tap % 3 - 1;
+        if (px < 36 && (unsigned)yy < 6u && (unsigned)xx < 6u) row = yy * 6 + xx;
+      } else if (tap == 0 && px < 36) {
+        row = px;
       }
-      return in + (ok ? row : SQ_ZERO) * SQ_LD + 32 * chunk + 16 * g + 4 * j;
-    };
-    auto advance = [&]() {
-      const int ng = (L.cin_p - 32 * chunk) >= 32 ? 2 : 1;
-      if (++g == ng) {
-        g = 0;
-        if (++tap == L.taps) { tap = 0; ++chunk; }
-      }
-    };
+      rowoff[tap] = row * SQ_LD + 4 * j;
+    }
+    rowoff[9] = SQ_ZERO * SQ_LD + 4 * j;
+    const int voff = ((j * L.cout_p + nt * 16 + r) * 4) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float4 bq[4];
+    f32x4 bq[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (i < nkk) bq[i] = *reinterpret_cast<const float4*>(wp + (size_t)i * kstride);
-    float4 a_cur = *reinterpret_cast<const float4*>(a_ptr());
-    for (int kk0 = 0; kk0 < nkk; kk0 += 4) {
+    for (int i = 0; i < 4; ++i) bq[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, i * kbytes, 0));
+    float4 av[2];
+    av[0] = *reinterpret_cast<const float4*>(in + rowoff[Wk::tap(0)] + Wk::col(0));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (kk0 + i < nkk) {
-          advance();
-          float4 a_nx = a_cur;
-          if (kk0 + i + 1 < nkk) a_nx = *reinterpret_cast<const float4*>(a_ptr());
-          const float4 b = bq[i];
-          if (kk0 + i + 4 < nkk) bq[i] = *reinterpret_cast<const float4*>(wp + (size_t)(kk0 + i + 4) * kstride);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.x, b.x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.y, b.y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.z, b.z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur.w, b.w, acc, 0, 0, 0);
-          a_cur = a_nx;
-        }
-      }
+    for (int kk = 0; kk < Wk::NKK4; ++kk) {
+      // the next group's activations (the last trip reads the zero row)
+      av[(kk + 1) & 1] = *reinterpret_cast<const float4*>(in + rowoff[Wk::tap(kk + 1)] + Wk::col(kk + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 a4 = av[kk & 1];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bq[kk & 3][0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bq[kk & 3][1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bq[kk & 3][2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bq[kk & 3][3], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // four groups ahead (all-zero groups past the end)
+      bq[kk & 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, (kk + 4) * kbytes, 0));
     }
     // accumulator: column (output channel) = lane & 15, rows (pixels) 4 j .. 4 j + 3
     const int col = nt * 16 + r;
@@ -141,17 +152,37 @@ __global__ __launch_bounds__(SQ_THREADS) void head_seq_kernel(SeqArgs a) {
   float* b0 = buf[0];
   float* b1 = buf[1];
   float* b2 = buf[2];
+  // the step's inputs (10 KB of fused features, the relative transform, the use flag) are fetched one step ahead into
+  // registers: their HBM latency runs under the previous step's convolutions
+  constexpr int NF = (72 * 36 + SQ_THREADS - 1) / SQ_THREADS;
+  float fnext[NF], rel_next = 0.f;
+  uint8_t use_next;
+  auto fetch = [&](int t) {
+    const size_t tr = (size_t)t * a.R + row;
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      const int i = tid + k * SQ_THREADS;
+      fnext[k] = i < 72 * 36 ? a.fused_t[tr * 72 * 36 + i] : 0.f;
+    }
+    use_next = a.use_t[tr];
+    if (tid < 12) rel_next = a.rel_t[tr * 12 + tid];
+  };
+  fetch(0);
   for (int t = 0; t < a.T; ++t) {
     const size_t tr = (size_t)t * a.R + row;
-    const bool use = a.use_t[tr] != 0;
-    if (tid < 12) srel[tid] = a.rel_t[tr * 12 + tid];
-    __syncthreads();
+    const bool use = use_next != 0;
+    if (tid < 12) srel[tid] = rel_next;
     // tin = [FTL(rel, memory) or 0 (18 channels), fused features (72), zeros (6)]  (temporal.py:59-85)
-    const float* fu = a.fused_t + tr * 72 * 36;
-    for (int i = tid; i < 72 * 36; i += SQ_THREADS) {
-      const int c = i / 36, p = i - c * 36;
-      b0[p * SQ_LD + sq_pos(18 + c)] = fu[i];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      const int i = tid + k * SQ_THREADS;
+      if (i < 72 * 36) {
+        const int c = i / 36, p = i - c * 36;
+        b0[p * SQ_LD + sq_pos(18 + c)] = fnext[k];
+      }
     }
+    __syncthreads();
+    if (t + 1 < a.T) fetch(t + 1);
     if (tid < 36 * 6) {
       const int c = tid % 6, p = tid / 6;
       float x = 0.f, y = 0.f, z = 0.f;
@@ -162,11 +193,11 @@ __global__ __launch_bounds__(SQ_THREADS) void head_seq_kernel(SeqArgs a) {
       b0[p * SQ_LD + sq_pos(90 + c)] = 0.f;
     }
     __syncthreads();
-    sq_conv(a.temp[0], b0, b1, nullptr, wave, lane);
+    sq_conv<1, 96>(a.temp[0], b0, b1, nullptr, wave, lane);
     __syncthreads();
-    sq_conv(a.temp[1], b1, b0, nullptr, wave, lane);
+    sq_conv<1, 96>(a.temp[1], b1, b0, nullptr, wave, lane);
     __syncthreads();
-    sq_conv(a.temp[2], b0, b1, nullptr, wave, lane);
+    sq_conv<1, 96>(a.temp[2], b0, b1, nullptr, wave, lane);
     __syncthreads();
     // channels 0..17 overwrite the memory, 18..89 go on with the skeleton channels behind them (temporal.py:88-89,
     // regressor.py:170-176)
@@ -184,15 +215,15 @@ __global__ __launch_bounds__(SQ_THREADS) void head_seq_kernel(SeqArgs a) {
       }
     }
     __syncthreads();
-    sq_conv(a.conv[0], b0, b1, nullptr, wave, lane);
+    sq_conv<9, 80>(a.conv[0], b0, b1, nullptr, wave, lane);
     __syncthreads();
-    sq_conv(a.conv[1], b1, b2, b0, wave, lane);
+    sq_conv<9, 80>(a.conv[1], b1, b2, b0, wave, lane);
     __syncthreads();
-    sq_conv(a.conv[2], b2, b1, nullptr, wave, lane);
+    sq_conv<9, 80>(a.conv[2], b2, b1, nullptr, wave, lane);
     __syncthreads();
-    sq_conv(a.conv[3], b1, b0, b2, wave, lane);
+    sq_conv<9, 80>(a.conv[3], b1, b0, b2, wave, lane);
     __syncthreads();
-    sq_conv(a.out, b0, b1, nullptr, wave, lane);
+    sq_conv<1, 80>(a.out, b0, b1, nullptr, wave, lane);
     __syncthreads();
     if (tid < a.nraw) {      // global average pool, pixel order as avgpool_kernel
       const int cp = sq_pos(tid);
@@ -250,9 +281,16 @@ int launch_head_sequence(const ConvLayer* temp, const ConvLayer* convs, const Co
                          const float* skel_axes, const float* skel_rest, int n_skel, const float* fused_t,
                          const float* cam0_t, const uint8_t* use_t, int T, int R, int nraw, float* mem, float* prev_ext,
                          int32_t* status, float** raw_t, void* workspace, hipStream_t s) {
-  for (int i = 0; i < 3; ++i) UMT_REQUIRE(temp[i].w16 && temp[i].cin <= 96 && temp[i].cout <= 96, UMT_ERR_STATE, "head_sequence: temporal layer %d not packed", i);
-  for (int i = 0; i < 4; ++i) UMT_REQUIRE(convs[i].w16 && convs[i].cin <= 96 && convs[i].cout <= 96, UMT_ERR_STATE, "head_sequence: regressor layer %d not packed", i);
-  UMT_REQUIRE(out.w16 && out.cout == nraw && nraw <= 64, UMT_ERR_STATE, "head_sequence: output layer not packed");
+  // the kernel is instantiated for the network's shapes: temporal 1x1 with 96 padded input channels, regressor 3x3 and
+  // the output 1x1 with 80 (76 or 72 channels, both heads)
+  for (int i = 0; i < 3; ++i)
+    UMT_REQUIRE(temp[i].w16 && temp[i].taps == 1 && round_up(temp[i].cin, 16) == 96 && temp[i].cout <= 96, UMT_ERR_STATE,
+                "head_sequence: temporal layer %d has an unexpected shape", i);
+  for (int i = 0; i < 4; ++i)
+    UMT_REQUIRE(convs[i].w16 && convs[i].taps == 9 && round_up(convs[i].cin, 16) == 80 && convs[i].cout <= 96, UMT_ERR_STATE,
+                "head_sequence: regressor layer %d has an unexpected shape", i);
+  UMT_REQUIRE(out.w16 && out.taps == 1 && round_up(out.cin, 16) == 80 && out.cout == nraw && nraw <= 64, UMT_ERR_STATE,
+              "head_sequence: output layer has an unexpected shape");
   char* ws = (char*)workspace;
   const int64_t n = (int64_t)T * R;
   float* rel_t = (float*)ws;                 ws += round_up64(n * 12 * 4, 256);

@@ -303,7 +303,9 @@ static void pack_conv_seq(const umt_model* m, std::vector<float>& host, std::vec
   const int cin_p = round_up(L->cin, 16), cout_p = round_up(L->cout, 16);
   static const int T4[4] = {0, 4, 1, 5};
   PackedSeq p{L, host.size()};
-  host.resize(host.size() + (size_t)L->taps * (cin_p / 16) * 4 * cout_p * 4, 0.f);
+  // padded with all-zero groups to a multiple of 4, plus the four groups the kernel's weight ring reads past the end
+  const size_t nkk4 = (((size_t)L->taps * (cin_p / 16) + 3) & ~(size_t)3) + 4;
+  host.resize(host.size() + nkk4 * 4 * cout_p * 4, 0.f);
   float* dst = host.data() + p.off;
   size_t kk = 0;
   for (int chunk = 0; chunk * 32 < cin_p; ++chunk) {
