@@ -382,6 +382,27 @@ def main():
     fin = mu.finalize_partials(pipe.partials)
     parity_pred = pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy()   # throughput-mode landmarks
 
+    # second mode of section 8(d): the same batch as 64-frame recordings in lock-step with the temporal
+    # memory ON (bulk backbone, then T sequential memory+regressor steps); per-rank, no collective
+    from umetrack_amd import bulk
+    runner = bulk.BulkSequenceRunner(pipe.model, pipe.wl.n_rec, pipe.wl.T, chunk_samples=pipe.chunk)
+    rec_valid = pipe.valid.view(-1, pipe.wl.T)
+
+    def recurrent_step():
+        runner.features(pipe.images, pipe.src_off, pipe.src_pitch, pipe.src_cams, pipe.dst_cams, pipe.K, pipe.E)
+        out = runner.run(pipe.E, pipe.hand_idx, pipe.skel, rec_valid)
+        skin_landmarks(pipe.hm, out.joint_angles, out.wrist_xfs, hand_idx=pipe.hand_idx, mirror_right=True,
+                       wrist_translation_scale=1000.0, out=pipe.pred_lm.view(-1, 21, 3))
+        return mu.metric_partials(pipe.gt_lm, pipe.pred_lm, pipe.valid)
+
+    def time_recurrent():
+        recurrent_step()
+        torch.cuda.synchronize()
+        tr0 = time.perf_counter()
+        partials = recurrent_step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - tr0, mu.finalize_partials(partials)
+
     # side measurements (rank 0's GPU only, no collective in them; never `value`): the same step in the two other
     # backbone modes, 1 warm-up + 2 timed steps each, backbone time from the library's HIP events
     def side_mode(precision, peak, note):
@@ -396,10 +417,14 @@ def main():
         dt = (time.perf_counter() - tx) / 2
         bb, fwd, ncalls = pipe.model.timing_read()
         pipe.model.timing_enable(False)
+        pred_side = pipe.pred_lm.clone()
+        rec_side_dt, _ = time_recurrent()
+        pipe.pred_lm.copy_(pred_side)
         pipe.model.precision = args.precision
         tf = BACKBONE_FLOP_PER_CROP * 2 * pipe.chunk / (bb / ncalls * 1e-3) / 1e12
         return {"value": pipe.S / dt, "unit": "hand-frames/s", "ms_per_step": dt * 1e3, "backbone_ms": bb / ncalls,
                 "forward_ms": fwd / ncalls, "backbone_tflops": tf, "peak_tflops": peak, "frac": tf / peak,
+                "recurrent_value": pipe.S / rec_side_dt, "recurrent_ms_per_step": rec_side_dt * 1e3,
                 "max_landmark_diff_vs_fp32_mm": float((pipe.pred_lm - pred32).abs().max()),
                 "mean_landmark_diff_vs_fp32_mm": float((pipe.pred_lm - pred32).abs().mean()),
                 "pred": pipe.pred_lm.view(-1, 21, 3)[:max(args.cpu_hands, 1)].cpu().numpy(), "note": note}
@@ -431,26 +456,7 @@ def main():
     for (_, e0), (name, e1) in zip(marks[:-1], marks[1:]):
         stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1)
 
-    # second mode of section 8(d): the same batch as 64-frame recordings in lock-step with the temporal
-    # memory ON (bulk backbone, then T sequential memory+regressor steps); per-rank, no collective
-    from umetrack_amd import bulk
-    runner = bulk.BulkSequenceRunner(pipe.model, pipe.wl.n_rec, pipe.wl.T, chunk_samples=pipe.chunk)
-    rec_valid = pipe.valid.view(-1, pipe.wl.T)
-
-    def recurrent_step():
-        runner.features(pipe.images, pipe.src_off, pipe.src_pitch, pipe.src_cams, pipe.dst_cams, pipe.K, pipe.E)
-        out = runner.run(pipe.E, pipe.hand_idx, pipe.skel, rec_valid)
-        skin_landmarks(pipe.hm, out.joint_angles, out.wrist_xfs, hand_idx=pipe.hand_idx, mirror_right=True,
-                       wrist_translation_scale=1000.0, out=pipe.pred_lm.view(-1, 21, 3))
-        return mu.metric_partials(pipe.gt_lm, pipe.pred_lm, pipe.valid)
-
-    recurrent_step()
-    torch.cuda.synchronize()
-    tr0 = time.perf_counter()
-    rec_partials = recurrent_step()
-    torch.cuda.synchronize()
-    rec_dt = time.perf_counter() - tr0
-    rec_fin = mu.finalize_partials(rec_partials)
+    rec_dt, rec_fin = time_recurrent()
 
     hands_per_step = pipe.S * world
     if rank != 0:
