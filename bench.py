@@ -464,8 +464,9 @@ def main():
     crops_per_call = 2 * pipe.chunk
     bf16 = args.precision == "bf16"
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_backbone_traffic.json")
-    if os.path.exists(tpath):      # PMC passes cannot run inside this process; see the file for provenance
+    tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_backbone_traffic.json") for r in (3, 2, 1))
+                  if os.path.exists(q)), "")
+    if tpath:      # PMC passes cannot run inside this process; see the file for provenance
         with open(tpath) as fh:
             tj = json.load(fh)
         tj = tj.get(args.precision, tj if not bf16 else {})
@@ -502,7 +503,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_note": peak_note, "traffic": traffic,
                      "traffic_note": "HBM bytes per forward call from rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
-                                     "profiles/r01_backbone_traffic.json (measured at 2048 crops/call, scaled per crop)",
+                                     f"profiles/{os.path.basename(tpath)} (separate --pmc passes of tools/round_profiles.sh; r02 on: measured at "
+                                     "16384 crops per forward call, the size of this run's calls)",
                      "hbm_view": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": hbm_achieved / HBM_PEAK_GBS,
                                   "note": "same launches priced by bytes: unfused input+output(+residual) rows of every "

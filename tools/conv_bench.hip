@@ -194,7 +194,7 @@ int main(int argc, char** argv) {
         unsigned s = 12345;
         for (size_t i = 0; i < hn; ++i) {
           s = s * 1664525u + 1013904223u;
-          const float v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f;
+          const float v = getenv("ZERO") ? 0.f : ((s >> 8) & 0xffff) / 65536.0f - 0.5f;      // ZERO=1: all-zero operands (clock / throttle diagnostic)
           if (bf) { unsigned u; memcpy(&u, &v, 4); const unsigned short b = (unsigned short)(u >> 16); memcpy(&h[i * 2], &b, 2); }
           else memcpy(&h[i * 4], &v, 4);
         }

@@ -15,11 +15,13 @@ for P in fp32 bf16 fp32x3; do
   python3 $ROOT/tools/layer_table.py $(find $OUT/lt_$P -name '*kernel_trace.csv' | head -1) 4096 > $OUT/layer_table_$P.txt
   tail -1 $OUT/layer_table_$P.txt
 done
-# 3. HBM traffic: separate PMC passes (FETCH_SIZE uses 3 TCC slots, WRITE_SIZE 2)
+# 3. HBM traffic: separate PMC passes (FETCH_SIZE uses 3 TCC slots, WRITE_SIZE 2), at the bench's call size
+#    (16384 crops in one forward call: 1.2 GB per stage-1 tensor, far beyond the 256 MB Infinity Cache)
+TC=16384
 for P in fp32 bf16 fp32x3; do
-  timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf_$P -o f --output-format csv -- python3 $ROOT/tools/profile_forward.py 2048 2 $P > $OUT/pf_$P.log 2>&1
-  timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pw_$P -o w --output-format csv -- python3 $ROOT/tools/profile_forward.py 2048 2 $P > $OUT/pw_$P.log 2>&1
-  python3 $ROOT/tools/traffic_json.py $(find $OUT/pf_$P -name '*counter_collection.csv' | head -1) $(find $OUT/pw_$P -name '*counter_collection.csv' | head -1) 2048 2 > $OUT/traffic_$P.json
+  timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d $OUT/pf_$P -o f --output-format csv -- python3 $ROOT/tools/profile_forward.py $TC 1 $P > $OUT/pf_$P.log 2>&1
+  timeout -s KILL 170 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pw_$P -o w --output-format csv -- python3 $ROOT/tools/profile_forward.py $TC 1 $P > $OUT/pw_$P.log 2>&1
+  python3 $ROOT/tools/traffic_json.py $(find $OUT/pf_$P -name '*counter_collection.csv' | head -1) $(find $OUT/pw_$P -name '*counter_collection.csv' | head -1) $TC 1 > $OUT/traffic_$P.json
   cat $OUT/traffic_$P.json
 done
 # 3b. matrix-pipe busy fraction and clock per kernel (its own PMC pass: 2 SQ + 1 GRBM counters)

@@ -2,7 +2,7 @@
 # copies what tools/round_profiles.sh left under gpurun_out/rp/ into profiles/ (run in the build container)
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r01}
+R=${1:-r02}
 cp $(find gpurun_out/rp/bench -name '*kernel_stats.csv' | head -1) profiles/${R}_bench_kernel_stats.csv
 for P in fp32 bf16 fp32x3; do
   python3 tools/layer_table.py gpurun_out/rp/lt_$P/t_kernel_trace.csv 4096 > profiles/${R}_layer_table_$P.txt
@@ -14,7 +14,8 @@ python3 - <<PY
 import json
 f=json.load(open('gpurun_out/rp/traffic_fp32.json')); b=json.load(open('gpurun_out/rp/traffic_bf16.json')); x=json.load(open('gpurun_out/rp/traffic_fp32x3.json'))
 p='profiles/${R}_backbone_traffic.json'
-old=json.load(open(p))
+import os
+old=json.load(open(p)) if os.path.exists(p) else {"note": "HBM bytes per crop of the backbone launches (stem + convolutions) from rocprofv3 --pmc passes over tools/profile_forward.py at 16384 crops per forward call (the bench's call size): FETCH_SIZE (x2: gfx950 reports half the bytes of 16-byte-per-lane streaming reads) and WRITE_SIZE, KiB units; tools/round_profiles.sh, tools/traffic_json.py"}
 old['fp32']=dict(f, algorithmic_bytes_per_crop=8396928); old['bf16']=dict(b, algorithmic_bytes_per_crop=4222080); old['fp32x3']=dict(x, algorithmic_bytes_per_crop=8396928)
 json.dump(old,open(p,'w'),indent=1)
 for q in ('fp32','bf16','fp32x3'):
