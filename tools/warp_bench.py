@@ -27,19 +27,25 @@ for path in sys.argv[1:]:
             rc = L.umt_warp_crops(nat.ptr(pipe.images), nat.ptr(pipe.src_off), nat.ptr(pipe.src_pitch), nat.ptr(pipe.src_cams),
                                   nat.ptr(pipe.dst_cams), n, 96, 96, mode, nat.ptr(out), nat.stream_ptr(dev))
             assert rc == 0
-        run()
+        for _ in range(60 if ref is None and mode == 0 else 10):   # clocks ramp up from idle over the first ~100 ms
+            run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5):
+        for _ in range(20):
             run()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
+        ms = e0.elapsed_time(e1) / 20
         note = ""
         if mode == 0:
             if ref is None:
                 ref = out.clone()
             else:
                 note = f"  differs from first lib in {(out != ref).float().mean().item():.4f} of pixels"
+        if hasattr(L, "umt_warp_stamps") and mode == 0:
+            st = (ctypes.c_ulonglong * 16)()
+            L.umt_warp_stamps(st)
+            names = ["nodes f64", "errors+cells", "interpolate", "queue", "bbox+reduce", "tile copy", "gather", "store"]
+            print("   s_memtime ticks (100 MHz) of workgroup 1000:", ", ".join(f"{names[i]} {st[i + 1] - st[i]}" for i in range(8)))
         print(f"{os.path.basename(path):28s} mode {mode}: {ms:7.3f} ms per {n} crops = {n * 73728 / ms / 1e9:6.2f} TB/s{note}", flush=True)

@@ -13,23 +13,28 @@
 // gathering from global memory.  Algorithmic traffic: 4 source bytes + 4 output bytes per pixel.
 //
 // The reference builds the map with float64 numpy and casts it to float32; OpenCV then rounds the
-// coordinate to 1/32 px.  In UMT_WARP_CV2_FIXED_POINT mode only that integer matters, so pass 1 runs
-// the camera model in float32 first (same formulas on a pre-multiplied rotation) and accepts the
-// result where the 1/32-px rounding cannot be affected by the float32 error (bound WARP_FAST_ULPS
-// relative roundings, 6x the largest error seen on the test and bench cameras).  The other pixels
-// (a few per cent: within the bound of a rounding boundary, near z = 0, not finite) are queued in
-// LDS and re-evaluated in float64 by the whole workgroup, densely.  UMT_WARP_CV2_FIXED_POINT_F64
-// evaluates every pixel in float64 (the tests hold the two modes bit-identical); UMT_WARP_FLOAT
-// always uses float64 maps.
+// coordinate to 1/32 px.  In UMT_WARP_CV2_FIXED_POINT mode only that integer matters, so pass 1 evaluates
+// the float64 map on a grid of 8-pixel spacing only and interpolates it bicubically in float32 in between,
+// accepting a pixel where the 1/32-px rounding cannot be affected by the MEASURED interpolation error of its
+// cell plus the float32 arithmetic bound (see "interpolated map" below).  The other pixels (about 5 per cent:
+// close to a rounding boundary, next to z = 0, not finite) are queued in LDS and re-evaluated in float64 by
+// the whole workgroup, densely.  UMT_WARP_CV2_FIXED_POINT_F64 evaluates every pixel in float64 (the tests
+// hold the two modes bit-identical); UMT_WARP_FLOAT always uses float64 maps.
 #include "umt_internal.h"
 
 namespace umt {
 
-constexpr int WARP_THREADS = 512;                // 8 waves per crop, 2 crops per CU: 4 waves per SIMD hide the maps' dependent chains
+#ifdef UMT_WARP_STAMP      // diagnostic builds only (tools/warp_bench.py): phase time stamps of one workgroup
+__device__ unsigned long long g_wstamp[16];
+#define WSTAMP(i) do { if (blockIdx.x == 1000 && threadIdx.x == 0) g_wstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WSTAMP(i) do {} while (0)
+#endif
+
+constexpr int WARP_THREADS = 512;                // 8 waves per crop, 2 crops per CU (128 registers: the float64 map beside 40 held coordinates does not fit 80)
 constexpr int WARP_MAX_PX = 20;                 // >= 96*96 / 512, as 5 groups of 4 consecutive pixels
 constexpr int WARP_LDS_BYTES = 60 * 1024;       // source rectangle budget (2 workgroups per CU)
 constexpr int WARP_QCAP = 3072;                 // float64 re-evaluation queue (aliases the rectangle: 30 KB)
-constexpr float WARP_FAST_ULPS = 12.0f;         // accepted float32 error of a source coordinate, in 2^-23 * |coordinate|
 
 struct SrcCam {
   double w, h, fx, fy, cx, cy, k1, k2, k3, k4, p1, p2, k5, k6, xf[16];
@@ -37,77 +42,6 @@ struct SrcCam {
 struct DstCam {
   double fx, fy, cx, cy, xf[16];
 };
-
-// float32 camera constants of one crop for the fast map
-struct FastCam {
-  float m[9], t[3];          // source-eye = m * crop-eye + t
-  float ifx, ify, dcx, dcy;  // crop camera
-  float fx, fy, cx, cy, k1, k2, k3, k4, k5, k6, p1, p2;
-};
-
-__device__ inline FastCam make_fast(const SrcCam& s, const DstCam& d) {
-  FastCam f;
-  for (int r = 0; r < 3; ++r) {
-    for (int c = 0; c < 3; ++c)
-      f.m[r * 3 + c] = (float)(s.xf[0 + r] * d.xf[0 + c] + s.xf[4 + r] * d.xf[4 + c] + s.xf[8 + r] * d.xf[8 + c]);
-    f.t[r] = (float)(s.xf[0 + r] * (d.xf[3] - s.xf[3]) + s.xf[4 + r] * (d.xf[7] - s.xf[7]) + s.xf[8 + r] * (d.xf[11] - s.xf[11]));
-  }
-  f.ifx = (float)(1.0 / d.fx); f.ify = (float)(1.0 / d.fy); f.dcx = (float)d.cx; f.dcy = (float)d.cy;
-  f.fx = (float)s.fx; f.fy = (float)s.fy; f.cx = (float)s.cx; f.cy = (float)s.cy;
-  f.k1 = (float)s.k1; f.k2 = (float)s.k2; f.k3 = (float)s.k3; f.k4 = (float)s.k4; f.k5 = (float)s.k5; f.k6 = (float)s.k6;
-  f.p1 = (float)s.p1; f.p2 = (float)s.p2;
-  return f;
-}
-
-// float32 map of one pixel -> 1/32-px integers.  Returns false when the float64 evaluation must decide.
-// Uses the hardware reciprocal / reciprocal-square-root / square-root (1 ulp each) and a degree-9
-// polynomial in a^2 for atan(a)/a on [0,1] (6e-8 relative in float32); all of it is inside the error
-// bound that decides whether the float32 result is accepted.
-__device__ inline bool map_point_fast(const FastCam& f, int u, int v, int& sx, int& sy) {
-  const float qx = ((float)u - f.dcx) * f.ifx, qy = ((float)v - f.dcy) * f.ify;
-  const float inv = __builtin_amdgcn_rsqf(qx * qx + qy * qy + 1.0f);
-  const float ex = qx * inv, ey = qy * inv, ez = inv;
-  const float x = f.m[0] * ex + f.m[1] * ey + f.m[2] * ez + f.t[0];
-  const float y = f.m[3] * ex + f.m[4] * ey + f.m[5] * ez + f.t[1];
-  const float z = f.m[6] * ex + f.m[7] * ey + f.m[8] * ez + f.t[2];
-  // depth check (tracker.py:71-73): the sign of z must be certain
-  const float zmag = fabsf(x) + fabsf(y) + fabsf(z);
-  if (!(fabsf(z) > 1e-4f * zmag)) return false;
-  if (z < 0.f) { sx = -32; sy = -32; return true; }
-  // sc = atan2(r, z) / r with z > 0: a = min/max, theta = a*P(a^2) or pi/2 - a*P(a^2)
-  const float r = __builtin_amdgcn_sqrtf(x * x + y * y);
-  const float inv_hi = __builtin_amdgcn_rcpf(fmaxf(r, z));
-  const float a = fminf(r, z) * inv_hi, s2 = a * a;
-  const float P = 1.0f + s2 * (-0.3333328366279602f + s2 * (0.1999826580286026f + s2 * (-0.142619326710701f + s2 * (0.1094203069806099f +
-                  s2 * (-0.08377315104007721f + s2 * (0.05755209922790527f + s2 * (-0.030804594978690147f + s2 * (0.01072694268077612f +
-                  s2 * -0.0017539297696202993f))))))));
-  const float sc = (r <= z ? P : 1.5707963267948966f - a * P) * inv_hi;
-  const float px = x * sc, py = y * sc;
-  const float r2 = fminf(px * px + py * py, 9.8696044f);
-  const float radial = 1.0f + r2 * (f.k1 + r2 * (f.k2 + r2 * (f.k3 + r2 * (f.k4 + r2 * (f.k5 + r2 * f.k6)))));
-  // relative sensitivity of the radial factor to r2: g / |radial| with g = r2 * |radial'|.  Where the
-  // distortion polynomial is steep (far off axis) the float32 error is amplified: leave it to float64.
-  const float dradial = f.k1 + r2 * (2.f * f.k2 + r2 * (3.f * f.k3 + r2 * (4.f * f.k4 + r2 * (5.f * f.k5 + r2 * 6.f * f.k6))));
-  const float g = r2 * fabsf(dradial), arad = fabsf(radial);
-  if (!(g <= 0.5f * arad)) return false;
-  const float ux = px * radial, uy = py * radial;
-  const float x2 = ux * ux, y2 = uy * uy, xy = ux * uy, rr = x2 + y2;
-  const float tx = 2.0f * f.p2 * xy + f.p1 * (rr + 2.0f * x2), ty = 2.0f * f.p1 * xy + f.p2 * (rr + 2.0f * y2);
-  const float dx = ux + tx, dy = uy + ty;
-  const float ox = dx * f.fx + f.cx, oy = dy * f.fy + f.cy;
-  if (!(fabsf(ox) < 30000.f && fabsf(oy) < 30000.f)) return false;          // also catches NaN
-  const float cx32 = ox * 32.0f, cy32 = oy * 32.0f;
-  const float rx = rintf(cx32), ry = rintf(cy32);
-  // distance to the nearest rounding boundary (k + 0.5) must exceed the error bound, in 1/32 px:
-  //   bound = 32 * (ULPS+1) * 2^-23 * (1 + 4 g/|radial|) * magnitude, magnitude = the largest value that
-  //   entered the coordinate; compared after multiplying through by |radial|
-  const float kb = 32.0f * (WARP_FAST_ULPS + 1.0f) * 1.1920929e-7f * (arad + 4.0f * g);
-  const float magx = fmaxf((fabsf(ux) + fabsf(tx)) * fabsf(f.fx) + fabsf(f.cx), 64.f);
-  const float magy = fmaxf((fabsf(uy) + fabsf(ty)) * fabsf(f.fy) + fabsf(f.cy), 64.f);
-  if (!((0.5f - fabsf(cx32 - rx)) * arad > kb * magx && (0.5f - fabsf(cy32 - ry)) * arad > kb * magy)) return false;
-  sx = (int)rx; sy = (int)ry;
-  return true;
-}
 
 __device__ inline void quantise_map(float mx, float my, int& sx, int& sy) {
   const float cx = fminf(fmaxf(mx * 32.0f, -1048576.f), 1048576.f);   // NaN -> lower bound
@@ -117,9 +51,10 @@ __device__ inline void quantise_map(float mx, float my, int& sx, int& sy) {
 }
 
 
-// window (u,v) of the crop camera -> window coordinates in the fisheye source, as float32
-template <bool DEPTH_CHECK = true>
-__device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v, float& mx, float& my) {
+// window (u,v) of the crop camera -> window coordinates in the fisheye source, float64; zc = cosine of the angle between
+// the ray and the source camera's axis times the ray length (z of the source-eye point)
+__device__ inline void map_point_raw(const SrcCam& s, const DstCam& d, int u, int v, double& ox, double& oy, double& zc,
+                                     double& plen2) {
   // camera.py:275-281 + PerspectiveProjection.unproject (camera.py:68-75) + affine.normalized
   double qx = ((double)u - d.cx) / d.fx, qy = ((double)v - d.cy) / d.fy;
   double nrm = fmax(5.43e-20, sqrt(qx * qx + qy * qy + 1.0));
@@ -146,21 +81,66 @@ __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v,
   double x2 = ux * ux, y2 = uy * uy, xy = ux * uy, rr = x2 + y2;
   double dx = ux + (2 * s.p2 * xy + s.p1 * (rr + 2 * x2));
   double dy = uy + (2 * s.p1 * xy + s.p2 * (rr + 2 * y2));
-  double ox = dx * s.fx + s.cx, oy = dy * s.fy + s.cy;
+  ox = dx * s.fx + s.cx;
+  oy = dy * s.fy + s.cy;
+  zc = z;
+  plen2 = x * x + y * y + z * z;
+}
+
+// the reference's map value of one pixel, as float32
+template <bool DEPTH_CHECK = true>
+__device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v, float& mx, float& my) {
+  double ox, oy, z, pl;
+  map_point_raw(s, d, u, v, ox, oy, z, pl);
   if (DEPTH_CHECK && z < 0) { ox = -1.0; oy = -1.0; }   // depth check, tracker.py:71-73
   mx = (float)ox;
   my = (float)oy;
 }
 
+// ---- interpolated map (UMT_WARP_CV2_FIXED_POINT, crops up to 96x96 whose camera shares the source camera's centre) ----
+// The map is smooth, so its float64 values on a grid of 8-pixel spacing (15x15 nodes from -8 to 104) determine it between
+// the nodes: bicubic Lagrange interpolation on the 4x4 nodes around a cell.  The interpolation error of every cell is
+// MEASURED, not assumed: the float64 map is also evaluated at the midpoints of the cell's four edges (where the error of the
+// 1-D cubic along that edge peaks) and at its centre, and a pixel's interpolated coordinate is accepted only when its
+// distance to the nearest 1/32-px rounding boundary exceeds twice the larger of (centre error, horizontal + vertical edge
+// error) plus the float32 arithmetic bound.  Nodes that are not regular (behind or within 1.1 degrees of the source camera's
+// z = 0 plane, not finite, out of range) are NaN and make every cell they touch undecided; undecided pixels go to the
+// float64 queue like those of the per-pixel float32 map.  All 16 nodes regular implies the cell is: with a shared centre the
+// set {z > 0.02 |p|} is a circular cone of rays, whose section with the crop's image plane is convex.
+constexpr int IG = 8;                       // grid spacing in pixels
+constexpr int IN = 96 / IG + 3;             // 15 nodes per axis: u = IG * (n - 1)
+constexpr int IC = 96 / IG;                 // 12 cells per axis
+constexpr int I_NODES = IN * IN;            // 225
+constexpr int I_HE = (IC + 1) * IC;         // 156 horizontal-edge midpoints (row r = 0..12, cell column c)
+constexpr int I_VE = IC * (IC + 1);         // 156 vertical-edge midpoints (cell row, column c = 0..12)
+constexpr int I_CE = IC * IC;               // 144 cell centres
+constexpr int I_EVALS = I_NODES + I_HE + I_VE + I_CE;   // 681 float64 evaluations per crop (7.4 % of the pixels)
+constexpr int I_OFF_DN = 30720;             // double2[681]  (the queue owns [0, 30720))
+constexpr int I_OFF_NF = I_OFF_DN + 16 * 688;        // float2[225] nodes relative to the centre node, 1/32 px
+constexpr int I_OFF_ERR = I_OFF_NF + 8 * 232;        // float[456] measured errors
+constexpr int I_OFF_CELL = I_OFF_ERR + 4 * 456;      // float[144] per-cell bound
+constexpr int I_OFF_WT = I_OFF_CELL + 4 * 144;       // float4[8] cubic weights of the 8 sub-positions
+static_assert(I_OFF_WT + 128 <= WARP_LDS_BYTES && I_OFF_WT % 16 == 0 && I_OFF_NF % 8 == 0, "interpolation tables");
+
+__device__ inline void interp_eval_pos(int e, int& u, int& v) {
+  if (e < I_NODES) { const int ny = e / IN, nx = e - ny * IN; u = IG * (nx - 1); v = IG * (ny - 1); }
+  else if (e < I_NODES + I_HE) { const int i = e - I_NODES, r = i / IC, c = i - r * IC; u = IG * c + IG / 2; v = IG * r; }
+  else if (e < I_NODES + I_HE + I_VE) { const int i = e - I_NODES - I_HE, cj = i / (IC + 1), c = i - cj * (IC + 1); u = IG * c; v = IG * cj + IG / 2; }
+  else { const int i = e - I_NODES - I_HE - I_VE, cj = i / IC, ci = i - cj * IC; u = IG * ci + IG / 2; v = IG * cj + IG / 2; }
+}
+
+__device__ inline float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }   // NaN if either is
+
 // pixel handled by slot i of thread tid: groups of 4 consecutive pixels, groups dealt round-robin to the threads
 __device__ __forceinline__ int warp_pixel(int tid, int i) { return 4 * (tid + (i >> 2) * WARP_THREADS) + (i & 3); }
 
+// LDS tile: row 0 and the last row are zero, every row starts and ends with a zero dword; source byte (x, y) of the
+// rectangle lives at (y - ty0) * tpitch + (x - tx0) with (tx0, ty0) the rectangle origin shifted by the border
 template <bool FROM_LDS>
 __device__ inline int fetch(const uint8_t* img, int pitch, int W, int H, const uint8_t* tile, int tx0, int ty0,
                             int tpitch, int y, int x) {
   if (x < 0 || y < 0 || x >= W || y >= H) return 0;   // BORDER_CONSTANT 0
-  if (FROM_LDS)    // LDS row = the source row from the 4-byte-aligned address at or below its first rectangle byte
-    return tile[(y - ty0) * tpitch + (x - tx0) + (int)((reinterpret_cast<uintptr_t>(img) + (size_t)y * pitch + tx0) & 3)];
+  if (FROM_LDS) return tile[(y - ty0) * tpitch + (x - tx0)];
   return img[(size_t)y * pitch + x];
 }
 
@@ -216,64 +196,195 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
   constexpr int smode = CV2 ? UMT_WARP_CV2_FIXED_POINT : UMT_WARP_FLOAT;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ int red[4][WARP_THREADS / 64];
-  __shared__ int qcount;
+  __shared__ int qcount, relmax_bits;
+  __shared__ float lut255[256];
   const int k = blockIdx.x;
   const int tid = threadIdx.x;
   const int W = (int)src_cams[(size_t)k * 30], H = (int)src_cams[(size_t)k * 30 + 1];
   const int pitch = src_pitch[k];
   const uint8_t* img = src_images + src_offset[k];
   const int npx = out_h * out_w;
+  WSTAMP(0);
+  if (tid < 256) lut255[tid] = (float)tid / 255.0f;      // read after the barriers below
 
   int sxs[WARP_MAX_PX], sys[WARP_MAX_PX];
   float mxs[CV2 ? 1 : WARP_MAX_PX], mys[CV2 ? 1 : WARP_MAX_PX];
 
   if (MODE == UMT_WARP_CV2_FIXED_POINT) {
-    // float32 map; pixels it cannot decide go to the queue: pixel ids, then their float64 results
+    // interpolated (or per-pixel float32) map; pixels it cannot decide go to the queue: pixel ids, then their float64 results
     uint16_t* qpix = reinterpret_cast<uint16_t*>(lds);
     int* qres = reinterpret_cast<int*>(lds + WARP_QCAP * 2);
-    if (tid == 0) qcount = 0;
-    __syncthreads();
-    FastCam f;
+    double2* dn = reinterpret_cast<double2*>(lds + I_OFF_DN);
+    float2* nf = reinterpret_cast<float2*>(lds + I_OFF_NF);
+    float* errs = reinterpret_cast<float*>(lds + I_OFF_ERR);
+    float* cell_e = reinterpret_cast<float*>(lds + I_OFF_CELL);
+    float4* wtab = reinterpret_cast<float4*>(lds + I_OFF_WT);
+    if (tid == 0) { qcount = 0; relmax_bits = 0; }
+    bool interp;
     {
       SrcCam s;
       DstCam d;
       load_cams(src_cams, dst_cams, k, s, d);
-      f = make_fast(s, d);
-    }
-    unsigned queued = 0;
-    int gu = 0, gv = 0;
-#pragma unroll
-    for (int i = 0; i < WARP_MAX_PX; ++i) {
-      const int p = warp_pixel(tid, i);
-      sxs[i] = sys[i] = -32;
-      bool undecided = false;
-      if (p < npx) {
-        if ((i & 3) == 0) { gv = p / out_w; gu = p - gv * out_w; }      // one division per group of 4 pixels
-        int u = gu + (i & 3), v = gv;
-        if (u >= out_w) { u -= out_w; ++v; }
-#ifdef UMT_WARP_X_NOMAP
-        sxs[i] = (int)(f.cx * 32.f) + 20 * u + 3 * v; sys[i] = (int)(f.cy * 32.f) + 21 * v - 2 * u;
-#else
-        undecided = !map_point_fast(f, u, v, sxs[i], sys[i]);
+      const double t0 = d.xf[3] - s.xf[3], t1 = d.xf[7] - s.xf[7], t2 = d.xf[11] - s.xf[11];
+      interp = out_w <= 96 && out_h <= 96 && (out_w & 3) == 0 && t0 * t0 + t1 * t1 + t2 * t2 <= 1e-12;   // uniform
+#ifdef UMT_WARP_X_NOINTERP
+      interp = false;
 #endif
-#ifdef UMT_WARP_X_NOQUEUE
-        if (undecided) { undecided = false; sxs[i] = sys[i] = 64; }
-#endif
-      }
-      if (undecided) {
-        const int pos = atomicAdd(&qcount, 1);
-        if (pos < WARP_QCAP) qpix[pos] = (uint16_t)p;
-        sxs[i] = pos;
-        queued |= 1u << i;
+      if (interp) {
+        for (int e = tid; e < I_EVALS; e += WARP_THREADS) {
+          int u, v;
+          interp_eval_pos(e, u, v);
+          double ox, oy, z, pl;
+          map_point_raw(s, d, u, v, ox, oy, z, pl);
+          const bool regular = z > 0 && z * z > 0.0004 * pl && fabs(ox) < 30000.0 && fabs(oy) < 30000.0;   // false for NaN
+          const double nan = __longlong_as_double(0x7ff8000000000000ll);
+          dn[e] = regular ? make_double2(ox * 32.0, oy * 32.0) : make_double2(nan, nan);
+        }
+        if (tid < IG) {
+          const float t = (float)tid / IG;
+          wtab[tid] = make_float4(-t * (t - 1) * (t - 2) / 6, (t + 1) * (t - 1) * (t - 2) / 2, -(t + 1) * t * (t - 2) / 2,
+                                  (t + 1) * t * (t - 1) / 6);
+        }
       }
     }
     __syncthreads();
+    WSTAMP(1);
+    unsigned queued = 0;
+    if (interp) {
+      const double2 ref = dn[(IN / 2) * IN + IN / 2];                 // the node at pixel (48, 48)
+      const double rix = floor(ref.x), riy = floor(ref.y);
+      if (tid < I_NODES) {
+        const double2 nv = dn[tid];
+        const float rx = (float)(nv.x - ref.x), ry = (float)(nv.y - ref.y);
+        nf[tid] = make_float2(rx, ry);
+        const float m = fmaxf(fabsf(rx), fabsf(ry));
+        if (rx == rx && ry == ry) atomicMax(&relmax_bits, __float_as_int(m));
+      }
+      if (tid < I_HE + I_VE + I_CE) {
+        // measured interpolation error at the check points (cubic weights at the midpoint: -1/16, 9/16, 9/16, -1/16)
+        double ix, iy;
+        if (tid < I_HE) {
+          const int r = tid / IC, c = tid - r * IC;
+          const double2* row = dn + (r + 1) * IN + c;
+          ix = (9.0 * (row[1].x + row[2].x) - (row[0].x + row[3].x)) * 0.0625;
+          iy = (9.0 * (row[1].y + row[2].y) - (row[0].y + row[3].y)) * 0.0625;
+        } else if (tid < I_HE + I_VE) {
+          const int i = tid - I_HE, cj = i / (IC + 1), c = i - cj * (IC + 1);
+          const double2* col = dn + cj * IN + c + 1;
+          ix = (9.0 * (col[IN].x + col[2 * IN].x) - (col[0].x + col[3 * IN].x)) * 0.0625;
+          iy = (9.0 * (col[IN].y + col[2 * IN].y) - (col[0].y + col[3 * IN].y)) * 0.0625;
+        } else {
+          const int i = tid - I_HE - I_VE, cj = i / IC, ci = i - cj * IC;
+          double rx[4], ry[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const double2* row = dn + (cj + m) * IN + ci;
+            rx[m] = (9.0 * (row[1].x + row[2].x) - (row[0].x + row[3].x)) * 0.0625;
+            ry[m] = (9.0 * (row[1].y + row[2].y) - (row[0].y + row[3].y)) * 0.0625;
+          }
+          ix = (9.0 * (rx[1] + rx[2]) - (rx[0] + rx[3])) * 0.0625;
+          iy = (9.0 * (ry[1] + ry[2]) - (ry[0] + ry[3])) * 0.0625;
+        }
+        const double2 ex = dn[I_NODES + tid];
+        const float ea = (float)fabs(ix - ex.x), eb = (float)fabs(iy - ex.y);
+        errs[tid] = nan_max(ea, eb) * 1.001f;
+      }
+      __syncthreads();
+      if (tid < I_CE) {
+        const int cj = tid / IC, ci = tid - cj * IC;
+        const float eh = nan_max(errs[cj * IC + ci], errs[(cj + 1) * IC + ci]);
+        const float ev = nan_max(errs[I_HE + cj * (IC + 1) + ci], errs[I_HE + cj * (IC + 1) + ci + 1]);
+        const float ec = errs[I_HE + I_VE + tid];
+        // float32 side of the bound: node values relative to the centre node are rounded to float32 (half an ulp of relmax
+        // each, cubic weights sum to <= 1.5625 in absolute value over the 16 nodes) and combined by 20 fused multiply-adds
+        cell_e[tid] = 2.0f * nan_max(ec, eh + ev) + 1.2e-7f * 8.0f * __int_as_float(relmax_bits) + 0.001f;
+      }
+      __syncthreads();
+      WSTAMP(2);
+      const float fxr = (float)(ref.x - rix), fyr = (float)(ref.y - riy);
+      const int irx = (int)rix, iry = (int)riy;
+#pragma unroll
+      for (int gq = 0; gq < WARP_MAX_PX / 4; ++gq) {
+        const int p = warp_pixel(tid, 4 * gq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sxs[4 * gq + j] = sys[4 * gq + j] = -32;
+        if (p < npx) {
+          const int gv = p / out_w, gu = p - gv * out_w;        // gu is a multiple of 4: the group lies in one cell
+          const int ci = gu >> 3, cj = gv >> 3;
+          const float4 wy = wtab[gv & 7];
+          const float2* nb = nf + cj * IN + ci;
+          float cx[4], cy[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float2 n0 = nb[c], n1 = nb[IN + c], n2 = nb[2 * IN + c], n3 = nb[3 * IN + c];
+            cx[c] = wy.x * n0.x + wy.y * n1.x + wy.z * n2.x + wy.w * n3.x;
+            cy[c] = wy.x * n0.y + wy.y * n1.y + wy.z * n2.y + wy.w * n3.y;
+          }
+          const float eb = cell_e[cj * IC + ci];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * gq + j;
+            const float4 wx = wtab[(gu & 7) + j];
+            const float tx = (wx.x * cx[0] + wx.y * cx[1] + wx.z * cx[2] + wx.w * cx[3]) + fxr;
+            const float ty = (wx.x * cy[0] + wx.y * cy[1] + wx.z * cy[2] + wx.w * cy[3]) + fyr;
+            const float rx = rintf(tx), ry = rintf(ty);
+            const float ax = fabsf((float)irx + tx), ay = fabsf((float)iry + ty);
+            // the reference rounds float32(coordinate) * 32: that cast moves the value by up to 2^-24 of its magnitude
+            const bool ok = (0.5f - fabsf(tx - rx)) > eb + 2.4e-7f * ax && (0.5f - fabsf(ty - ry)) > eb + 2.4e-7f * ay &&
+                            ax < 960000.f && ay < 960000.f;
+            sxs[i] = irx + (int)rx;                 // replaced by the queue position below when not accepted
+            sys[i] = iry + (int)ry;
+#ifndef UMT_WARP_X_NOQUEUE
+            queued |= ok ? 0u : 1u << i;
+#endif
+          }
+        }
+      }
+    } else {
+      // other crop sizes, or a crop camera that does not share the source camera's centre: every pixel in float64
+      // (more than the queue holds, so each thread evaluates its own pixels below)
+#pragma unroll
+      for (int i = 0; i < WARP_MAX_PX; ++i) {
+        sxs[i] = sys[i] = -32;
+        if (warp_pixel(tid, i) < npx) queued |= 1u << i;
+      }
+    }
+    // queue slots: one LDS atomic per wave (a per-pixel atomic on one address serialises the whole workgroup)
+    {
+      const int cnt = __popc(queued), lane = tid & 63;
+      int incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+      }
+      int base = 0;
+      if (lane == 63 && incl > 0) base = atomicAdd(&qcount, incl);
+      base = __shfl(base, 63);
+      int pos = base + incl - cnt;
+#pragma unroll
+      for (int i = 0; i < WARP_MAX_PX; ++i)
+        if ((queued >> i) & 1u) {
+          if (pos < WARP_QCAP) qpix[pos] = (uint16_t)warp_pixel(tid, i);
+          sxs[i] = pos++;
+        }
+    }
+    __syncthreads();
+    WSTAMP(3);
     const int nq = qcount;
     SrcCam s;
     DstCam d;
     if (nq > 0) load_cams(src_cams, dst_cams, k, s, d);
-    if (nq <= WARP_QCAP) {
-      for (int q = tid; q < nq; q += WARP_THREADS) {
+    // the queue in windows of WARP_QCAP entries (one window unless the crop is degenerate): a single float64 code site
+    for (int w0 = 0; w0 < nq; w0 += WARP_QCAP) {          // uniform
+      if (w0 > 0) {
+#pragma unroll
+        for (int i = 0; i < WARP_MAX_PX; ++i)
+          if (((queued >> i) & 1u) && sxs[i] < w0 + WARP_QCAP) qpix[sxs[i] - w0] = (uint16_t)warp_pixel(tid, i);
+        __syncthreads();     // also: the previous window's results have been read
+      }
+      const int n = min(nq - w0, WARP_QCAP);
+      for (int q = tid; q < n; q += WARP_THREADS) {
         const int p = qpix[q];
         const int v = p / out_w, u = p - v * out_w;
         float mx, my;
@@ -286,20 +397,11 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < WARP_MAX_PX; ++i)
-        if ((queued >> i) & 1u) {
-          const int pos = sxs[i];
+        if (((queued >> i) & 1u) && sxs[i] < w0 + WARP_QCAP) {    // positions below w0 were resolved (bit cleared) earlier
+          const int pos = sxs[i] - w0;
           sxs[i] = qres[2 * pos];
           sys[i] = qres[2 * pos + 1];
-        }
-    } else {          // degenerate crop: every thread re-evaluates its own undecided pixels
-#pragma unroll
-      for (int i = 0; i < WARP_MAX_PX; ++i)
-        if ((queued >> i) & 1u) {
-          const int p = warp_pixel(tid, i);
-          const int v = p / out_w, u = p - v * out_w;
-          float mx, my;
-          map_point(s, d, u, v, mx, my);
-          quantise_map(mx, my, sxs[i], sys[i]);
+          queued &= ~(1u << i);
         }
     }
   } else {
@@ -326,6 +428,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
     }
   }
 
+  WSTAMP(4);
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = -(1 << 30), by1 = -(1 << 30);
 #pragma unroll
   for (int i = 0; i < WARP_MAX_PX; ++i) {
@@ -347,6 +450,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
     red[0][tid >> 6] = bx0; red[1][tid >> 6] = by0; red[2][tid >> 6] = bx1; red[3][tid >> 6] = by1;
   }
   __syncthreads();          // also: every read of the re-evaluation queue is done before the rectangle overwrites it
+  WSTAMP(5);
   bx0 = red[0][0]; by0 = red[1][0]; bx1 = red[2][0]; by1 = red[3][0];
 #pragma unroll
   for (int wv = 1; wv < WARP_THREADS / 64; ++wv) {
@@ -357,8 +461,14 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
   bx1 = min(bx1, W - 1); by1 = min(by1, H - 1);
   const bool empty = bx1 < bx0 || by1 < by0;
   const int tw = empty ? 0 : bx1 - bx0 + 1, th = empty ? 0 : by1 - by0 + 1;
-  const int tpitch = ((tw + 3) & ~3) + 4;          // bytes per LDS row: rectangle width + alignment slack, dword multiple
-  const bool use_lds = !empty && (int64_t)tpitch * th <= WARP_LDS_BYTES;   // uniform over the workgroup
+  // LDS tile = the rectangle with a zero border: rows 0 and th + 1 are zero, every row is [zero dword][dwords covering
+  // source bytes bx0 - mis .. bx0 + tw, bytes outside the rectangle masked to zero][zero dword].  A tap outside the image
+  // but next to the rectangle then reads 0 (BORDER_CONSTANT) with no test of its own.
+  const bool aligned = (pitch & 3) == 0;           // then every row starts at the same offset within a dword
+  const int mis = aligned ? (int)((reinterpret_cast<uintptr_t>(img) + (size_t)by0 * pitch + bx0) & 3) : 0;
+  const int tpd = ((mis + tw + 3) >> 2) + 2;       // dwords per LDS row
+  const int tpitch = tpd * 4;
+  const bool use_lds = !empty && (int64_t)tpitch * (th + 2) <= WARP_LDS_BYTES;   // uniform over the workgroup
 
   float res[WARP_MAX_PX];
 #ifdef UMT_WARP_X_NOGATHER
@@ -368,24 +478,57 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
   } else
 #endif
   if (use_lds) {
-    // aligned 4-byte copies: LDS row r holds the dwords that cover source bytes [bx0, bx0 + tw) of row by0 + r
-    const int tpd = tpitch >> 2;
-    const int total = tpd * th;
     uint32_t* lds32 = reinterpret_cast<uint32_t*>(lds);
+    // flat over the tile's dwords, four independent loads in flight per thread; row = idx / tpd through a float reciprocal
+    // (exact: idx < 2^14).  Border dwords load a clamped in-rectangle address and store 0.
+    const float inv_tpd = 1.0f / (float)tpd;
+    const int total = tpd * (th + 2);
+    const uint8_t* g0 = img + (size_t)by0 * pitch + bx0 - mis;
+    if (aligned) {
 #pragma unroll 4
-    for (int idx = tid; idx < total; idx += WARP_THREADS) {
-      const int row = idx / tpd, col = idx - row * tpd;
-      const uintptr_t a0 = (reinterpret_cast<uintptr_t>(img) + (size_t)(by0 + row) * pitch + bx0) & ~(uintptr_t)3;
-      const int mis = (int)((reinterpret_cast<uintptr_t>(img) + (size_t)(by0 + row) * pitch + bx0) & 3);
-      uint32_t v = 0;
-      if (4 * col < mis + tw) v = *reinterpret_cast<const uint32_t*>(a0 + 4 * (size_t)col);
-      lds32[idx] = v;
+      for (int idx = tid; idx < total; idx += WARP_THREADS) {
+        const int row = (int)(((float)idx + 0.5f) * inv_tpd), c = idx - row * tpd;
+        const bool data = row >= 1 && row <= th && c >= 1 && c < tpd - 1;
+        const int b0 = 4 * (min(max(c, 1), tpd - 2) - 1);     // byte offset of this dword from the row's aligned start
+        uint32_t v = *reinterpret_cast<const uint32_t*>(g0 + (size_t)(min(max(row, 1), th) - 1) * pitch + b0);
+        const int start = mis - b0, end = mis + tw - b0;      // rectangle bytes are [start, end) of the dword
+        if (start > 0) v &= 0xffffffffu << (8 * start);
+        if (end < 4) v &= (1u << (8 * end)) - 1u;
+        lds32[idx] = data ? v : 0u;
+      }
+    } else {
+      for (int idx = tid; idx < total; idx += WARP_THREADS) {
+        const int row = (int)(((float)idx + 0.5f) * inv_tpd), c = idx - row * tpd;
+        uint32_t v = 0;
+        if (row >= 1 && row <= th && c >= 1 && c < tpd - 1) {
+          const uint8_t* g = g0 + (size_t)(row - 1) * pitch;
+          const int b0 = 4 * (c - 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (b0 + j < tw) v |= (uint32_t)g[b0 + j] << (8 * j);
+        }
+        lds32[idx] = v;
+      }
     }
     __syncthreads();
+    WSTAMP(6);
+    if constexpr (CV2) {
+      // [external] OpenCV 8-bit INTER_LINEAR: 1/32-px coordinates, 15-bit weights, round to nearest
+      const int cst = (1 - by0) * tpitch + 4 + mis - bx0;
 #pragma unroll
-    for (int i = 0; i < WARP_MAX_PX; ++i)
-      res[i] = sample<true>(smode, img, pitch, W, H, lds, bx0, by0, tpitch, sxs[i], sys[i], CV2 ? 0.f : mxs[i],
-                            CV2 ? 0.f : mys[i]);
+      for (int i = 0; i < WARP_MAX_PX; ++i) {
+        const int ix = sxs[i] >> 5, iy = sys[i] >> 5, fx = sxs[i] & 31, fy = sys[i] & 31;
+        const bool inside = (unsigned)(ix + 1) <= (unsigned)W && (unsigned)(iy + 1) <= (unsigned)H;   // footprint touches the image
+        const int idx = inside ? iy * tpitch + ix + cst : 0;       // byte 0: its four taps are border zeros
+        const int a = lds[idx], b = lds[idx + 1], c = lds[idx + tpitch], d = lds[idx + tpitch + 1];
+        const int acc = (a * ((32 - fy) * (32 - fx)) + b * ((32 - fy) * fx) + c * (fy * (32 - fx)) + d * (fy * fx)) * 32;
+        res[i] = lut255[(acc + (1 << 14)) >> 15];                 // tracker.py:211, v / 255 as a correctly rounded float32
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < WARP_MAX_PX; ++i)
+        res[i] = sample<true>(smode, img, pitch, W, H, lds, bx0 - 4 - mis, by0 - 1, tpitch, sxs[i], sys[i], mxs[i], mys[i]);
+    }
   } else {
 #pragma unroll
     for (int i = 0; i < WARP_MAX_PX; ++i)
@@ -393,6 +536,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
                    ? sample<false>(smode, img, pitch, W, H, lds, 0, 0, 0, sxs[i], sys[i], CV2 ? 0.f : mxs[i], CV2 ? 0.f : mys[i])
                    : 0.f;
   }
+  WSTAMP(7);
   float* obase = out + (size_t)k * npx;
   const bool vec = (npx & 3) == 0;               // then every group of 4 is whole and 16-byte aligned
 #pragma unroll
@@ -406,6 +550,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
         if (p + j < npx) obase[p + j] = res[4 * gq + j];
     }
   }
+  WSTAMP(8);
 }
 
 // data_transform.py:78-144, one thread per output pixel, float64 coordinates like the reference
@@ -459,6 +604,12 @@ extern "C" int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offs
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+#ifdef UMT_WARP_STAMP
+extern "C" int umt_warp_stamps(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(umt::g_wstamp), 16 * sizeof(unsigned long long));
+}
+#endif
 
 extern "C" int umt_resample_pinhole(const float* images, const float* xfs, int n, int h, int w, int out_h, int out_w,
                                     float* out, void* stream) {
