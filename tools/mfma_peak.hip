@@ -1,0 +1,114 @@
+// What the matrix pipe of THIS chip sustains in loops with no memory traffic at all (experiments only, not part of the
+// library): the practical ceiling the convolution kernels are compared with in DESIGN.md beside the datasheet peak.
+//   hipcc -O3 --offload-arch=gfx950 tools/mfma_peak.hip -o tools/bin/mfma_peak && tools/bin/mfma_peak
+// Every wave runs ITERS x 8 independent MFMAs on register operands (8 accumulator tiles, so issue is back to back), one or
+// two waves per SIMD, all 256 CUs.  The LDS variants re-read both operands with ds_read_b128 before every MFMA pair, which
+// is what a 2x2-tile GEMM inner loop does.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int ITERS = 8192;
+
+__device__ inline float rnd(unsigned x) {   // hash -> (-1, 1): operand bits toggle like real activations / weights
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(int)x * (1.0f / 2147483648.0f);
+}
+
+__global__ __launch_bounds__(256) void k_bf16_32(float* out, float seed) {
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)rnd(threadIdx.x * 16 + i + (unsigned)seed); b[i] = (__bf16)rnd(threadIdx.x * 16 + 8 + i + blockIdx.x * 4096); }
+  f32x16 acc[8] = {};
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][7];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_bf16_16(float* out, float seed) {
+  bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)rnd(threadIdx.x * 16 + i + (unsigned)seed); b[i] = (__bf16)rnd(threadIdx.x * 16 + 8 + i + blockIdx.x * 4096); }
+  f32x4 acc[16] = {};
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void k_f32_32(float* out, float seed) {
+  const float a = rnd(threadIdx.x + (unsigned)seed), b = rnd(threadIdx.x * 3 + 1 + blockIdx.x * 4096);
+  f32x16 acc[8] = {};
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][7];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// 2x2 tiles of 32x32x16: per k-step two A and two B fragments come from LDS (conflict-free 16-byte rows), four MFMAs
+__global__ __launch_bounds__(256) void k_bf16_32_lds(float* out, float seed) {
+  __shared__ __attribute__((aligned(16))) __bf16 sa[2][64 * 8 * 4], sb[2][64 * 8 * 4];
+  for (int i = threadIdx.x; i < 64 * 8 * 4; i += 256) {
+    sa[0][i] = (__bf16)rnd(i + (unsigned)seed); sa[1][i] = (__bf16)rnd(i + 77777);
+    sb[0][i] = (__bf16)rnd(i + 33333 + blockIdx.x * 4096); sb[1][i] = (__bf16)rnd(i + 55555);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x16 acc[4] = {};
+  for (int it = 0; it < ITERS * 2; ++it) {
+    const int o = (wave * 64 + lane) * 8 + 0 * (it & 1);
+    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&sa[0][o]), a1 = *reinterpret_cast<const bf16x8*>(&sa[1][o]);
+    const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&sb[0][o]), b1 = *reinterpret_cast<const bf16x8*>(&sb[1][o]);
+    asm volatile("" ::: "memory");
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[1], 0, 0, 0);
+    acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[2], 0, 0, 0);
+    acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[3], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int t = 0; t < 4; ++t) s += acc[t][0] + acc[t][7];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <typename K>
+static void run(const char* name, K kern, double flop_per_wave, int waves_per_simd, float* out) {
+  const int blocks = 256 * waves_per_simd;          // 256-thread workgroups: one wave per SIMD each
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1.0f);   // clocks settle
+  (void)hipDeviceSynchronize();
+  const int reps = 100;
+  (void)hipEventRecord(e0, 0);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1.0f + i);
+  (void)hipEventRecord(e1, 0);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  const double flops = flop_per_wave * 4.0 * blocks * reps;
+  printf("%-44s %d wave(s)/SIMD: %8.1f TFLOP/s  (%.3f ms per launch)\n", name, waves_per_simd, flops / (ms * 1e-3) / 1e12, ms / reps);
+}
+
+int main() {
+  float* out;
+  if (hipMalloc(&out, 256 * 2 * 256 * sizeof(float)) != hipSuccess) return 1;
+  for (int w = 1; w <= 2; ++w) {
+    run("bf16 32x32x16, register operands", k_bf16_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 16, w, out);
+    run("bf16 16x16x32, register operands", k_bf16_16, (double)ITERS * 16 * 2.0 * 16 * 16 * 32, w, out);
+    run("bf16 32x32x16, 2x2 tile, operands from LDS", k_bf16_32_lds, (double)ITERS * 2 * 4 * 2.0 * 32 * 32 * 16, w, out);
+    run("fp32 32x32x2, register operands", k_f32_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 2, w, out);
+  }
+  (void)hipFree(out);
+  return 0;
+}

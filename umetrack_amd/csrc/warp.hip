@@ -330,8 +330,9 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
             const float rx = rintf(tx), ry = rintf(ty);
             const float ax = fabsf((float)irx + tx), ay = fabsf((float)iry + ty);
             // the reference rounds float32(coordinate) * 32: that cast moves the value by up to 2^-24 of its magnitude
-            const bool ok = (0.5f - fabsf(tx - rx)) > eb + 2.4e-7f * ax && (0.5f - fabsf(ty - ry)) > eb + 2.4e-7f * ay &&
-                            ax < 960000.f && ay < 960000.f;
+            // (bitwise: a short-circuit chain becomes four nested branches per pixel)
+            const bool ok = (int)((0.5f - fabsf(tx - rx)) > eb + 2.4e-7f * ax) & (int)((0.5f - fabsf(ty - ry)) > eb + 2.4e-7f * ay) &
+                            (int)(ax < 960000.f) & (int)(ay < 960000.f);
             sxs[i] = irx + (int)rx;                 // replaced by the queue position below when not accepted
             sys[i] = iry + (int)ry;
 #ifndef UMT_WARP_X_NOQUEUE
@@ -518,7 +519,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
 #pragma unroll
       for (int i = 0; i < WARP_MAX_PX; ++i) {
         const int ix = sxs[i] >> 5, iy = sys[i] >> 5, fx = sxs[i] & 31, fy = sys[i] & 31;
-        const bool inside = (unsigned)(ix + 1) <= (unsigned)W && (unsigned)(iy + 1) <= (unsigned)H;   // footprint touches the image
+        const bool inside = (int)((unsigned)(ix + 1) <= (unsigned)W) & (int)((unsigned)(iy + 1) <= (unsigned)H);   // footprint touches the image
         const int idx = inside ? iy * tpitch + ix + cst : 0;       // byte 0: its four taps are border zeros
         const int a = lds[idx], b = lds[idx + 1], c = lds[idx + tpitch], d = lds[idx + tpitch + 1];
         const int acc = (a * ((32 - fy) * (32 - fx)) + b * ((32 - fy) * fx) + c * (fy * (32 - fx)) + d * (fy * fx)) * 32;
