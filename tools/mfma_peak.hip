@@ -13,6 +13,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int ITERS = 8192;
+__device__ unsigned long long g_ticks[2];   // s_memtime at the start / end of workgroup 0's first wave
+#define TICK(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ticks[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ inline float rnd(unsigned x) {   // hash -> (-1, 1): operand bits toggle like real activations / weights
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -23,10 +25,12 @@ __global__ __launch_bounds__(256) void k_bf16_32(float* out, float seed) {
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)rnd(threadIdx.x * 16 + i + (unsigned)seed); b[i] = (__bf16)rnd(threadIdx.x * 16 + 8 + i + blockIdx.x * 4096); }
   f32x16 acc[8] = {};
+  TICK(0);
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[t], 0, 0, 0);
   }
+  TICK(1);
   float s = 0.f;
   for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][7];
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -36,10 +40,12 @@ __global__ __launch_bounds__(256) void k_bf16_16(float* out, float seed) {
   bf16x8 a, b;
   for (int i = 0; i < 8; ++i) { a[i] = (__bf16)rnd(threadIdx.x * 16 + i + (unsigned)seed); b[i] = (__bf16)rnd(threadIdx.x * 16 + 8 + i + blockIdx.x * 4096); }
   f32x4 acc[16] = {};
+  TICK(0);
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
   }
+  TICK(1);
   float s = 0.f;
   for (int t = 0; t < 16; ++t) s += acc[t][0] + acc[t][3];
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -48,10 +54,12 @@ __global__ __launch_bounds__(256) void k_bf16_16(float* out, float seed) {
 __global__ __launch_bounds__(256) void k_f32_32(float* out, float seed) {
   const float a = rnd(threadIdx.x + (unsigned)seed), b = rnd(threadIdx.x * 3 + 1 + blockIdx.x * 4096);
   f32x16 acc[8] = {};
+  TICK(0);
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
   }
+  TICK(1);
   float s = 0.f;
   for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][7];
   out[blockIdx.x * 256 + threadIdx.x] = s;
@@ -67,6 +75,7 @@ __global__ __launch_bounds__(256) void k_bf16_32_lds(float* out, float seed) {
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x16 acc[4] = {};
+  TICK(0);
   for (int it = 0; it < ITERS * 2; ++it) {
     const int o = (wave * 64 + lane) * 8 + 0 * (it & 1);
     const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&sa[0][o]), a1 = *reinterpret_cast<const bf16x8*>(&sa[1][o]);
@@ -77,13 +86,14 @@ __global__ __launch_bounds__(256) void k_bf16_32_lds(float* out, float seed) {
     acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[2], 0, 0, 0);
     acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[3], 0, 0, 0);
   }
+  TICK(1);
   float s = 0.f;
   for (int t = 0; t < 4; ++t) s += acc[t][0] + acc[t][7];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
 template <typename K>
-static void run(const char* name, K kern, double flop_per_wave, int waves_per_simd, float* out) {
+static void run(const char* name, K kern, double flop_per_wave, double mfma_per_wave, int waves_per_simd, float* out) {
   const int blocks = 256 * waves_per_simd;          // 256-thread workgroups: one wave per SIMD each
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -97,17 +107,21 @@ static void run(const char* name, K kern, double flop_per_wave, int waves_per_si
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
   const double flops = flop_per_wave * 4.0 * blocks * reps;
-  printf("%-44s %d wave(s)/SIMD: %8.1f TFLOP/s  (%.3f ms per launch)\n", name, waves_per_simd, flops / (ms * 1e-3) / 1e12, ms / reps);
+  unsigned long long t[2];
+  (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(g_ticks), sizeof(t));
+  const double ticks = (double)(t[1] - t[0]);
+  printf("%-44s %d wave(s)/SIMD: %8.1f TFLOP/s  (%.3f ms per launch; s_memtime ticks per MFMA of one wave %.1f, ticks per us %.0f)\n", name,
+         waves_per_simd, flops / (ms * 1e-3) / 1e12, ms / reps, ticks / mfma_per_wave, ticks / (ms / reps * 1e3));
 }
 
 int main() {
   float* out;
   if (hipMalloc(&out, 256 * 2 * 256 * sizeof(float)) != hipSuccess) return 1;
   for (int w = 1; w <= 2; ++w) {
-    run("bf16 32x32x16, register operands", k_bf16_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 16, w, out);
-    run("bf16 16x16x32, register operands", k_bf16_16, (double)ITERS * 16 * 2.0 * 16 * 16 * 32, w, out);
-    run("bf16 32x32x16, 2x2 tile, operands from LDS", k_bf16_32_lds, (double)ITERS * 2 * 4 * 2.0 * 32 * 32 * 16, w, out);
-    run("fp32 32x32x2, register operands", k_f32_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 2, w, out);
+    run("bf16 32x32x16, register operands", k_bf16_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 16, ITERS * 8.0, w, out);
+    run("bf16 16x16x32, register operands", k_bf16_16, (double)ITERS * 16 * 2.0 * 16 * 16 * 32, ITERS * 16.0, w, out);
+    run("bf16 32x32x16, 2x2 tile, operands from LDS", k_bf16_32_lds, (double)ITERS * 2 * 4 * 2.0 * 32 * 32 * 16, ITERS * 8.0, w, out);
+    run("fp32 32x32x2, register operands", k_f32_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 2, ITERS * 8.0, w, out);
   }
   (void)hipFree(out);
   return 0;

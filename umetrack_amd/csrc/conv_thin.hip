@@ -452,8 +452,12 @@ constexpr int S128_WMAX = 12;
 constexpr int S128_CBYTES = 3 * 128 * 4;
 constexpr int S128_RING = 6;
 
+#ifndef UMT_S128_MI
+#define UMT_S128_MI 2     // 32-pixel tiles per wave: 2 -> waves 2 x 2 (64 px x 64 channels), 4 -> waves 1 x 4 (128 px x 32 channels)
+#endif
 template <bool RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
+  constexpr int MI = UMT_S128_MI, NI = 4 / MI, WAVES_N = 4 / NI;
   constexpr int BM = S128_BM;
   constexpr int NLD = ((BM + 2 * S128_WMAX + 2) * 16 + 255) / 256;   // uint4 slots per thread for one halo range
   constexpr int R = S128_RING, NK = 72;
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
   const int W = a.W, H = a.H;
   const int rows = BM + 2 * W + 2;
   const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6, group = threadIdx.x >> 8;
-  const int wm = wave >> 1, wn = wave & 1;                          // a wave owns 64 pixels x 64 channels
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;              // a wave owns MI*32 pixels x NI*32 channels
   const int a_bytes = ((rows + 1) * S128_LDA * 2 + 15) & ~15;      // halo range + the all-zero row
   const float* sC = reinterpret_cast<const float*>(smem_s);
   unsigned char* sA = smem_s + S128_CBYTES + group * (a_bytes + 4 * 32 * T_LDP * 4);
@@ -486,13 +490,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
   // weight fragments: packed [tap][8 groups of 16 channels][2][128][8] bf16; scalar (tap, group) offset, one lane offset
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, 9 * 128 * 128 * 2, 0x00020000);
-  const int wvoff = ((lh * 128) + wn * 64 + li) * 16;
-  uint4 bk[R][2];
-  auto load_bk = [&](uint4 (&dst)[2], int ks) {       // ks = chunk * 18 + tap * 2 + c
+  const int wvoff = ((lh * 128) + wn * NI * 32 + li) * 16;
+  uint4 bk[R][NI];
+  auto load_bk = [&](uint4 (&dst)[NI], int ks) {       // ks = chunk * 18 + tap * 2 + c
     const int chunk = ks / 18, tap = (ks % 18) >> 1, c16 = chunk * 2 + (ks & 1);
     const int soff = (tap * 8 + c16) * 4096;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NI; ++n) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + n * 512, soff, 0);
       dst[n] = make_uint4(v.x, v.y, v.z, v.w);
     }
@@ -531,40 +535,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
   }
   __syncthreads();
 
-  f32x16 acc[2][2];
-  uint4 res[2][2][2];
+  f32x16 acc[MI][NI];
+  uint4 res[MI][NI][2];
   for (int ph = 0; ph < nphase; ++ph) {
     STAMP(ph, 0);
     const int j = (ph - group) >> 1;
     const bool mfma_phase = ((ph - group) & 1) == 0;
     if (ph >= group && j < gw.count) {
       const int t = gw.first + j * gw.step;
-      const int mw = t * BM + wm * 64;
+      const int mw = t * BM + wm * MI * 32;
       if (mfma_phase) {
 #pragma unroll
         for (int s0 = 0; s0 < R - 1; ++s0) load_bk(bk[s0], s0);
-        int arow[2][9];      // byte offset of the lane's operand row per tap; the zero row where padded
+        int arow[MI][9];      // byte offset of the lane's operand row per tap; the zero row where padded
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MI; ++i) {
           const unsigned mk = border_mask(mw + i * 32 + li, a.M, H, W, a.mg_hw, a.mg_w);
 #pragma unroll
           for (int tap = 0; tap < 9; ++tap)
-            arow[i][tap] = ((((mk >> tap) & 1u) ? wm * 64 + i * 32 + li + (tap / 3) * W + (tap % 3) : rows) * S128_LDA + 8 * lh) * 2;
+            arow[i][tap] = ((((mk >> tap) & 1u) ? wm * MI * 32 + i * 32 + li + (tap / 3) * W + (tap % 3) : rows) * S128_LDA + 8 * lh) * 2;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
+          for (int n = 0; n < NI; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][n][r] = 0.f;
         // A fragments run one k-step ahead of their MFMAs: in an MFMA phase this wave is the only one on its SIMD that
         // issues matrix instructions (its partner is in the epilogue), so a read waited for in its own k-step leaves
         // the pipe idle for the whole LDS latency (measured: 236 cycles per k-step against 128 of MFMA)
-        uint4 av[2][2];
-        auto read_a = [&](uint4 (&dst)[2], int ks) {
+        uint4 av[2][MI];
+        auto read_a = [&](uint4 (&dst)[MI], int ks) {
           const int tap = (ks % 18) >> 1, c16 = (ks / 18) * 2 + (ks & 1);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) dst[i] = *reinterpret_cast<const uint4*>(sA + arow[i][tap] + c16 * 32);
+          for (int i = 0; i < MI; ++i) dst[i] = *reinterpret_cast<const uint4*>(sA + arow[i][tap] + c16 * 32);
         };
         read_a(av[0], 0);
 #pragma unroll
@@ -574,13 +578,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
             if (j + 1 < gw.count) load_a(t + gw.step);
             if (RES) {
 #pragma unroll
-              for (int i = 0; i < 2; ++i)
+              for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < NI; ++n)
 #pragma unroll
                   for (int k = 0; k < 2; ++k) {
                     const int m = mw + i * 32 + 16 * k + rsub;
-                    const size_t off = m < a.M ? (size_t)m * 128 + wn * 64 + n * 32 + 8 * q : 0;
+                    const size_t off = m < a.M ? (size_t)m * 128 + wn * NI * 32 + n * 32 + 8 * q : 0;
                     res[i][n][k] = *reinterpret_cast<const uint4*>(resid + off);
                   }
             }
@@ -588,21 +592,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
           if (ks + 1 < NK) read_a(av[(ks + 1) & 1], ks + 1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NI; ++n)
               acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ks & 1][i]),
                                                                   __builtin_bit_cast(bf16x8, bk[ks % R][n]), acc[i][n], 0, 0, 0);
         }
       } else {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const int co = wn * 64 + n * 32 + 8 * q;
+        for (int n = 0; n < NI; ++n) {
+          const int co = wn * NI * 32 + n * 32 + 8 * q;
           const float4 cb0 = *reinterpret_cast<const float4*>(sC + co), cb1 = *reinterpret_cast<const float4*>(sC + co + 4);
           const float4 cs0 = *reinterpret_cast<const float4*>(sC + 128 + co), cs1 = *reinterpret_cast<const float4*>(sC + 128 + co + 4);
           const float4 ch0 = *reinterpret_cast<const float4*>(sC + 256 + co), ch1 = *reinterpret_cast<const float4*>(sC + 256 + co + 4);
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
+          for (int i = 0; i < MI; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * T_LDP + li] = acc[i][n][r];
             __builtin_amdgcn_wave_barrier();
