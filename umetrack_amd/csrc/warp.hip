@@ -6,7 +6,7 @@
 //  * umt_resample_pinhole - pinhole -> pinhole float bilinear, replaces _resample_images_batched
 //                         (lib/batched_dataset/data_transform.py:78-144).
 //
-// One workgroup per crop.  Pass 1 evaluates the coordinate map and keeps the 20 fixed-point
+// One workgroup per band of 32 rows of a crop.  Pass 1 evaluates the coordinate map and keeps the 12 fixed-point
 // coordinates per thread in registers while the workgroup reduces their bounding box.  Pass 2
 // copies that source rectangle into LDS with coalesced row reads, pass 3 gathers the four taps
 // from LDS and writes whole 384-B output rows.  Rectangles that do not fit fall back to
@@ -31,10 +31,15 @@ __device__ unsigned long long g_wstamp[16];
 #define WSTAMP(i) do {} while (0)
 #endif
 
-constexpr int WARP_THREADS = 512;                // 8 waves per crop, 2 crops per CU (128 registers: the float64 map beside 40 held coordinates does not fit 80)
-constexpr int WARP_MAX_PX = 20;                 // >= 96*96 / 512, as 5 groups of 4 consecutive pixels
-constexpr int WARP_LDS_BYTES = 60 * 1024;       // source rectangle budget (2 workgroups per CU)
-constexpr int WARP_QCAP = 3072;                 // float64 re-evaluation queue (aliases the rectangle: 30 KB)
+constexpr int WARP_THREADS = 256;                // one workgroup = a band of rows of one crop; 4-5 bands share a CU, so a band's
+                                                 // barrier-separated phases (latency chains) overlap with other bands' phases
+constexpr int WARP_MAX_PX = 12;                 // pixels per thread, as 3 groups of 4 consecutive pixels
+constexpr int WARP_BAND_PX = WARP_MAX_PX * WARP_THREADS;   // 3072 pixels per band: 32 rows of a 96-wide crop
+constexpr int WARP_LDS_BYTES = 24 * 1024;       // source rectangle budget of a band
+#ifndef WARP_WAVES_PER_SIMD
+#define WARP_WAVES_PER_SIMD 4
+#endif
+constexpr int WARP_QCAP = 1024;                 // float64 re-evaluation queue window (10 KB; the rectangle later reuses the space)
 
 struct SrcCam {
   double w, h, fx, fy, cx, cy, k1, k2, k3, k4, p1, p2, k5, k6, xf[16];
@@ -97,36 +102,37 @@ __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v,
   my = (float)oy;
 }
 
-// ---- interpolated map (UMT_WARP_CV2_FIXED_POINT, crops up to 96x96 whose camera shares the source camera's centre) ----
-// The map is smooth, so its float64 values on a grid of 8-pixel spacing (15x15 nodes from -8 to 104) determine it between
+// ---- interpolated map (UMT_WARP_CV2_FIXED_POINT, crops up to 96 wide whose camera shares the source camera's centre) ----
+// The map is smooth, so its float64 values on a grid of 8-pixel spacing (15 x 7 nodes around a band of 32 rows) determine it between
 // the nodes: bicubic Lagrange interpolation on the 4x4 nodes around a cell.  The interpolation error of every cell is
 // MEASURED, not assumed: the float64 map is also evaluated at the midpoints of the cell's four edges (where the error of the
-// 1-D cubic along that edge peaks) and at its centre, and a pixel's interpolated coordinate is accepted only when its
-// distance to the nearest 1/32-px rounding boundary exceeds twice the larger of (centre error, horizontal + vertical edge
-// error) plus the float32 arithmetic bound.  Nodes that are not regular (behind or within 1.1 degrees of the source camera's
+// 1-D cubic along that edge peaks; the error of the tensor-product interpolant inside the cell is the sum of the two 1-D
+// errors to leading order), and a pixel's interpolated coordinate is accepted only when its distance to the nearest 1/32-px
+// rounding boundary exceeds twice (larger horizontal-edge error + larger vertical-edge error) plus the float32 arithmetic bound.  Nodes that are not regular (behind or within 1.1 degrees of the source camera's
 // z = 0 plane, not finite, out of range) are NaN and make every cell they touch undecided; undecided pixels go to the
 // float64 queue like those of the per-pixel float32 map.  All 16 nodes regular implies the cell is: with a shared centre the
 // set {z > 0.02 |p|} is a circular cone of rays, whose section with the crop's image plane is convex.
 constexpr int IG = 8;                       // grid spacing in pixels
-constexpr int IN = 96 / IG + 3;             // 15 nodes per axis: u = IG * (n - 1)
-constexpr int IC = 96 / IG;                 // 12 cells per axis
-constexpr int I_NODES = IN * IN;            // 225
-constexpr int I_HE = (IC + 1) * IC;         // 156 horizontal-edge midpoints (row r = 0..12, cell column c)
-constexpr int I_VE = IC * (IC + 1);         // 156 vertical-edge midpoints (cell row, column c = 0..12)
-constexpr int I_CE = IC * IC;               // 144 cell centres
-constexpr int I_EVALS = I_NODES + I_HE + I_VE + I_CE;   // 681 float64 evaluations per crop (7.4 % of the pixels)
-constexpr int I_OFF_DN = 30720;             // double2[681]  (the queue owns [0, 30720))
-constexpr int I_OFF_NF = I_OFF_DN + 16 * 688;        // float2[225] nodes relative to the centre node, 1/32 px
-constexpr int I_OFF_ERR = I_OFF_NF + 8 * 232;        // float[456] measured errors
-constexpr int I_OFF_CELL = I_OFF_ERR + 4 * 456;      // float[144] per-cell bound
-constexpr int I_OFF_WT = I_OFF_CELL + 4 * 144;       // float4[8] cubic weights of the 8 sub-positions
+constexpr int IBH = 32;                     // rows of a band on the interpolated path
+constexpr int INX = 96 / IG + 3;            // 15 node columns: u = IG * (nx - 1)
+constexpr int INY = IBH / IG + 3;           // 7 node rows of a band: v = v0 + IG * (ny - 1)
+constexpr int ICX = 96 / IG, ICY = IBH / IG;   // 12 x 4 cells
+constexpr int I_NODES = INX * INY;          // 105
+constexpr int I_HE = (ICY + 1) * ICX;       // 60 horizontal-edge midpoints (row r = 0..4, cell column c)
+constexpr int I_VE = ICY * (ICX + 1);       // 52 vertical-edge midpoints (cell row, column c = 0..12)
+constexpr int I_EVALS = I_NODES + I_HE + I_VE;   // 217 float64 evaluations per band of 3072 pixels: one per thread
+static_assert(I_EVALS <= WARP_THREADS && IBH * 96 == WARP_BAND_PX, "one evaluation per thread, one band per workgroup");
+constexpr int I_OFF_DN = WARP_QCAP * 10;             // double2[217]  (the queue owns [0, 10 * QCAP): 2-byte ids, 8-byte results)
+constexpr int I_OFF_NF = I_OFF_DN + 16 * 218;        // float2[105] nodes relative to the band's centre node, 1/32 px
+constexpr int I_OFF_ERR = I_OFF_NF + 8 * 106;        // float[112] measured errors
+constexpr int I_OFF_CELL = I_OFF_ERR + 4 * 112;      // float[48] per-cell bound
+constexpr int I_OFF_WT = I_OFF_CELL + 4 * 48;        // float4[8] cubic weights of the 8 sub-positions
 static_assert(I_OFF_WT + 128 <= WARP_LDS_BYTES && I_OFF_WT % 16 == 0 && I_OFF_NF % 8 == 0, "interpolation tables");
 
-__device__ inline void interp_eval_pos(int e, int& u, int& v) {
-  if (e < I_NODES) { const int ny = e / IN, nx = e - ny * IN; u = IG * (nx - 1); v = IG * (ny - 1); }
-  else if (e < I_NODES + I_HE) { const int i = e - I_NODES, r = i / IC, c = i - r * IC; u = IG * c + IG / 2; v = IG * r; }
-  else if (e < I_NODES + I_HE + I_VE) { const int i = e - I_NODES - I_HE, cj = i / (IC + 1), c = i - cj * (IC + 1); u = IG * c; v = IG * cj + IG / 2; }
-  else { const int i = e - I_NODES - I_HE - I_VE, cj = i / IC, ci = i - cj * IC; u = IG * ci + IG / 2; v = IG * cj + IG / 2; }
+__device__ inline void interp_eval_pos(int e, int v0, int& u, int& v) {
+  if (e < I_NODES) { const int ny = e / INX, nx = e - ny * INX; u = IG * (nx - 1); v = v0 + IG * (ny - 1); }
+  else if (e < I_NODES + I_HE) { const int i = e - I_NODES, r = i / ICX, c = i - r * ICX; u = IG * c + IG / 2; v = v0 + IG * r; }
+  else { const int i = e - I_NODES - I_HE, cj = i / (ICX + 1), c = i - cj * (ICX + 1); u = IG * c; v = v0 + IG * cj + IG / 2; }
 }
 
 __device__ inline float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }   // NaN if either is
@@ -186,24 +192,24 @@ __device__ inline void load_cams(const double* __restrict__ src_cams, const doub
 // MODE: UMT_WARP_CV2_FIXED_POINT (float32 map + float64 re-evaluation queue), UMT_WARP_FLOAT,
 // UMT_WARP_CV2_FIXED_POINT_F64 (every pixel in float64)
 template <int MODE, bool DEPTH_CHECK = true>
-__global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __restrict__ src_images,
+__global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel(const uint8_t* __restrict__ src_images,
                                                             const int64_t* __restrict__ src_offset,
                                                             const int32_t* __restrict__ src_pitch,
                                                             const double* __restrict__ src_cams,
                                                             const double* __restrict__ dst_cams, int out_h, int out_w,
-                                                            float* __restrict__ out) {
+                                                            int band_h, int nbands, float* __restrict__ out) {
   constexpr bool CV2 = MODE != UMT_WARP_FLOAT;
   constexpr int smode = CV2 ? UMT_WARP_CV2_FIXED_POINT : UMT_WARP_FLOAT;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   __shared__ int red[4][WARP_THREADS / 64];
   __shared__ int qcount, relmax_bits;
   __shared__ float lut255[256];
-  const int k = blockIdx.x;
+  const int k = blockIdx.x / nbands, v0 = (blockIdx.x - k * nbands) * band_h;     // crop, first row of this band
   const int tid = threadIdx.x;
   const int W = (int)src_cams[(size_t)k * 30], H = (int)src_cams[(size_t)k * 30 + 1];
   const int pitch = src_pitch[k];
   const uint8_t* img = src_images + src_offset[k];
-  const int npx = out_h * out_w;
+  const int npx = min(band_h, out_h - v0) * out_w;         // pixels of this band; pixel p is (p % out_w, v0 + p / out_w)
   WSTAMP(0);
   if (tid < 256) lut255[tid] = (float)tid / 255.0f;      // read after the barriers below
 
@@ -226,14 +232,15 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
       DstCam d;
       load_cams(src_cams, dst_cams, k, s, d);
       const double t0 = d.xf[3] - s.xf[3], t1 = d.xf[7] - s.xf[7], t2 = d.xf[11] - s.xf[11];
-      interp = out_w <= 96 && out_h <= 96 && (out_w & 3) == 0 && t0 * t0 + t1 * t1 + t2 * t2 <= 1e-12;   // uniform
+      interp = out_w <= 96 && band_h == IBH && (out_w & 3) == 0 && t0 * t0 + t1 * t1 + t2 * t2 <= 1e-12;   // uniform
 #ifdef UMT_WARP_X_NOINTERP
       interp = false;
 #endif
       if (interp) {
-        for (int e = tid; e < I_EVALS; e += WARP_THREADS) {
+        if (tid < I_EVALS) {
+          const int e = tid;
           int u, v;
-          interp_eval_pos(e, u, v);
+          interp_eval_pos(e, v0, u, v);
           double ox, oy, z, pl;
           map_point_raw(s, d, u, v, ox, oy, z, pl);
           const bool regular = z > 0 && z * z > 0.0004 * pl && fabs(ox) < 30000.0 && fabs(oy) < 30000.0;   // false for NaN
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
     WSTAMP(1);
     unsigned queued = 0;
     if (interp) {
-      const double2 ref = dn[(IN / 2) * IN + IN / 2];                 // the node at pixel (48, 48)
+      const double2 ref = dn[(INY / 2) * INX + INX / 2];              // the node at pixel (48, v0 + 16)
       const double rix = floor(ref.x), riy = floor(ref.y);
       if (tid < I_NODES) {
         const double2 nv = dn[tid];
@@ -260,44 +267,35 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
         const float m = fmaxf(fabsf(rx), fabsf(ry));
         if (rx == rx && ry == ry) atomicMax(&relmax_bits, __float_as_int(m));
       }
-      if (tid < I_HE + I_VE + I_CE) {
+      if (tid < I_HE + I_VE) {
         // measured interpolation error at the check points (cubic weights at the midpoint: -1/16, 9/16, 9/16, -1/16)
         double ix, iy;
         if (tid < I_HE) {
-          const int r = tid / IC, c = tid - r * IC;
-          const double2* row = dn + (r + 1) * IN + c;
+          const int r = tid / ICX, c = tid - r * ICX;
+          const double2* row = dn + (r + 1) * INX + c;
           ix = (9.0 * (row[1].x + row[2].x) - (row[0].x + row[3].x)) * 0.0625;
           iy = (9.0 * (row[1].y + row[2].y) - (row[0].y + row[3].y)) * 0.0625;
-        } else if (tid < I_HE + I_VE) {
-          const int i = tid - I_HE, cj = i / (IC + 1), c = i - cj * (IC + 1);
-          const double2* col = dn + cj * IN + c + 1;
-          ix = (9.0 * (col[IN].x + col[2 * IN].x) - (col[0].x + col[3 * IN].x)) * 0.0625;
-          iy = (9.0 * (col[IN].y + col[2 * IN].y) - (col[0].y + col[3 * IN].y)) * 0.0625;
         } else {
-          const int i = tid - I_HE - I_VE, cj = i / IC, ci = i - cj * IC;
-          double rx[4], ry[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) {
-            const double2* row = dn + (cj + m) * IN + ci;
-            rx[m] = (9.0 * (row[1].x + row[2].x) - (row[0].x + row[3].x)) * 0.0625;
-            ry[m] = (9.0 * (row[1].y + row[2].y) - (row[0].y + row[3].y)) * 0.0625;
-          }
-          ix = (9.0 * (rx[1] + rx[2]) - (rx[0] + rx[3])) * 0.0625;
-          iy = (9.0 * (ry[1] + ry[2]) - (ry[0] + ry[3])) * 0.0625;
+          const int i = tid - I_HE, cj = i / (ICX + 1), c = i - cj * (ICX + 1);
+          const double2* col = dn + cj * INX + c + 1;
+          ix = (9.0 * (col[INX].x + col[2 * INX].x) - (col[0].x + col[3 * INX].x)) * 0.0625;
+          iy = (9.0 * (col[INX].y + col[2 * INX].y) - (col[0].y + col[3 * INX].y)) * 0.0625;
         }
         const double2 ex = dn[I_NODES + tid];
         const float ea = (float)fabs(ix - ex.x), eb = (float)fabs(iy - ex.y);
         errs[tid] = nan_max(ea, eb) * 1.001f;
       }
       __syncthreads();
-      if (tid < I_CE) {
-        const int cj = tid / IC, ci = tid - cj * IC;
-        const float eh = nan_max(errs[cj * IC + ci], errs[(cj + 1) * IC + ci]);
-        const float ev = nan_max(errs[I_HE + cj * (IC + 1) + ci], errs[I_HE + cj * (IC + 1) + ci + 1]);
-        const float ec = errs[I_HE + I_VE + tid];
-        // float32 side of the bound: node values relative to the centre node are rounded to float32 (half an ulp of relmax
-        // each, cubic weights sum to <= 1.5625 in absolute value over the 16 nodes) and combined by 20 fused multiply-adds
-        cell_e[tid] = 2.0f * nan_max(ec, eh + ev) + 1.2e-7f * 8.0f * __int_as_float(relmax_bits) + 0.001f;
+      if (tid < ICX * ICY) {
+        const int cj = tid / ICX, ci = tid - cj * ICX;
+        const float eh = nan_max(errs[cj * ICX + ci], errs[(cj + 1) * ICX + ci]);
+        const float ev = nan_max(errs[I_HE + cj * (ICX + 1) + ci], errs[I_HE + cj * (ICX + 1) + ci + 1]);
+        // float32 side of the bound, worst case, with u = 2^-24 and R = relmax (largest node value relative to the centre
+        // node): a node is rounded to float32 (u R); the column combination is 4 roundings of partial sums <= 1.25 R (the
+        // cubic weights sum to <= 1.25 in absolute value), 3 u relative error of each weight, and the node errors: 10 u R;
+        // the row combination adds 4 roundings of sums <= 1.5625 R, the weights again and 1.25 x the column error:
+        // 23.5 u R = 1.4e-6 R in all, plus the final addition (u (R + 1))
+        cell_e[tid] = 2.0f * (eh + ev) + 1.6e-6f * __int_as_float(relmax_bits) + 0.001f;
       }
       __syncthreads();
       WSTAMP(2);
@@ -309,24 +307,32 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
 #pragma unroll
         for (int j = 0; j < 4; ++j) sxs[4 * gq + j] = sys[4 * gq + j] = -32;
         if (p < npx) {
-          const int gv = p / out_w, gu = p - gv * out_w;        // gu is a multiple of 4: the group lies in one cell
+          const int gv = p / out_w, gu = p - gv * out_w;        // band-local row; gu is a multiple of 4: the group lies in one cell
           const int ci = gu >> 3, cj = gv >> 3;
+          // (x, y) pairs through packed fused multiply-adds: 16 for the column combination, 4 per pixel; the chain order is
+          // fixed here because the error bound in cell_e counts its roundings
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
           const float4 wy = wtab[gv & 7];
-          const float2* nb = nf + cj * IN + ci;
-          float cx[4], cy[4];
+          const f32x2* nb = reinterpret_cast<const f32x2*>(nf) + cj * INX + ci;
+          f32x2 cc[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float2 n0 = nb[c], n1 = nb[IN + c], n2 = nb[2 * IN + c], n3 = nb[3 * IN + c];
-            cx[c] = wy.x * n0.x + wy.y * n1.x + wy.z * n2.x + wy.w * n3.x;
-            cy[c] = wy.x * n0.y + wy.y * n1.y + wy.z * n2.y + wy.w * n3.y;
+            f32x2 t = nb[c] * (f32x2){wy.x, wy.x};
+            t = __builtin_elementwise_fma((f32x2){wy.y, wy.y}, nb[INX + c], t);
+            t = __builtin_elementwise_fma((f32x2){wy.z, wy.z}, nb[2 * INX + c], t);
+            cc[c] = __builtin_elementwise_fma((f32x2){wy.w, wy.w}, nb[3 * INX + c], t);
           }
-          const float eb = cell_e[cj * IC + ci];
+          const float eb = cell_e[cj * ICX + ci];
+          const f32x2 fr = {fxr, fyr};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int i = 4 * gq + j;
             const float4 wx = wtab[(gu & 7) + j];
-            const float tx = (wx.x * cx[0] + wx.y * cx[1] + wx.z * cx[2] + wx.w * cx[3]) + fxr;
-            const float ty = (wx.x * cy[0] + wx.y * cy[1] + wx.z * cy[2] + wx.w * cy[3]) + fyr;
+            f32x2 t = cc[0] * (f32x2){wx.x, wx.x};
+            t = __builtin_elementwise_fma((f32x2){wx.y, wx.y}, cc[1], t);
+            t = __builtin_elementwise_fma((f32x2){wx.z, wx.z}, cc[2], t);
+            t = __builtin_elementwise_fma((f32x2){wx.w, wx.w}, cc[3], t) + fr;
+            const float tx = t.x, ty = t.y;
             const float rx = rintf(tx), ry = rintf(ty);
             const float ax = fabsf((float)irx + tx), ay = fabsf((float)iry + ty);
             // the reference rounds float32(coordinate) * 32: that cast moves the value by up to 2^-24 of its magnitude
@@ -387,9 +393,9 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
       const int n = min(nq - w0, WARP_QCAP);
       for (int q = tid; q < n; q += WARP_THREADS) {
         const int p = qpix[q];
-        const int v = p / out_w, u = p - v * out_w;
+        const int vl = p / out_w, u = p - vl * out_w;
         float mx, my;
-        map_point(s, d, u, v, mx, my);
+        map_point(s, d, u, v0 + vl, mx, my);
         int sx, sy;
         quantise_map(mx, my, sx, sy);
         qres[2 * q] = sx;
@@ -415,9 +421,9 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
       sxs[i] = sys[i] = -32;
       if (!CV2) mxs[i] = mys[i] = -1.f;
       if (p < npx) {
-        const int v = p / out_w, u = p - v * out_w;
+        const int vl = p / out_w, u = p - vl * out_w;
         float mx, my;
-        map_point<DEPTH_CHECK>(s, d, u, v, mx, my);
+        map_point<DEPTH_CHECK>(s, d, u, v0 + vl, mx, my);
         if (CV2) {
           quantise_map(mx, my, sxs[i], sys[i]);
         } else {
@@ -433,14 +439,12 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
   int bx0 = 1 << 30, by0 = 1 << 30, bx1 = -(1 << 30), by1 = -(1 << 30);
 #pragma unroll
   for (int i = 0; i < WARP_MAX_PX; ++i) {
-    const int p = warp_pixel(tid, i);
-    if (p < npx) {
-      const int ix = CV2 ? sxs[i] >> 5 : sxs[i], iy = CV2 ? sys[i] >> 5 : sys[i];
-      if (ix + 1 >= 0 && ix < W && iy + 1 >= 0 && iy < H) {   // footprint touches the image
-        bx0 = min(bx0, ix); bx1 = max(bx1, ix + 1);
-        by0 = min(by0, iy); by1 = max(by1, iy + 1);
-      }
-    }
+    const int ix = CV2 ? sxs[i] >> 5 : sxs[i], iy = CV2 ? sys[i] >> 5 : sys[i];
+    // footprint touches the image: ix in [-1, W - 1] and iy in [-1, H - 1] (selects, not branches)
+    const bool in = (int)((unsigned)(ix + 1) <= (unsigned)W) & (int)((unsigned)(iy + 1) <= (unsigned)H) &
+                    (int)(warp_pixel(tid, i) < npx);
+    bx0 = min(bx0, in ? ix : 1 << 30); bx1 = max(bx1, in ? ix + 1 : -(1 << 30));
+    by0 = min(by0, in ? iy : 1 << 30); by1 = max(by1, in ? iy + 1 : -(1 << 30));
   }
   // workgroup bounding box of the source footprint
   for (int o = 32; o > 0; o >>= 1) {
@@ -538,8 +542,8 @@ __global__ __launch_bounds__(WARP_THREADS, 4) void warp_kernel(const uint8_t* __
                    : 0.f;
   }
   WSTAMP(7);
-  float* obase = out + (size_t)k * npx;
-  const bool vec = (npx & 3) == 0;               // then every group of 4 is whole and 16-byte aligned
+  float* obase = out + (size_t)k * out_h * out_w + (size_t)v0 * out_w;
+  const bool vec = (((out_h * out_w) | (band_h * out_w) | npx) & 3) == 0;   // then every group of 4 is whole and 16-byte aligned
 #pragma unroll
   for (int gq = 0; gq < WARP_MAX_PX / 4; ++gq) {
     const int p = warp_pixel(tid, 4 * gq);
@@ -587,8 +591,12 @@ extern "C" int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offs
   using namespace umt;
   if (n == 0) return 0;
   UMT_REQUIRE(n > 0 && out_h > 0 && out_w >= 4, UMT_ERR_INVALID, "warp: n=%d out=%dx%d (width must be >= 4)", n, out_h, out_w);
-  UMT_REQUIRE(out_h * out_w <= WARP_MAX_PX * WARP_THREADS, UMT_ERR_UNSUPPORTED,
-              "warp: crops larger than %d pixels are not supported (got %dx%d)", WARP_MAX_PX * WARP_THREADS, out_w, out_h);
+  UMT_REQUIRE(out_w <= WARP_BAND_PX, UMT_ERR_UNSUPPORTED, "warp: crops wider than %d pixels are not supported (got %d)",
+              WARP_BAND_PX, out_w);
+  // a workgroup takes a band of rows: 32 for crops up to 96 wide (the interpolated map's band), else what fits its registers
+  const int band_h = out_w <= 96 ? IBH : WARP_BAND_PX / out_w;
+  const int nbands = (out_h + band_h - 1) / band_h;
+  UMT_REQUIRE((int64_t)n * nbands < ((int64_t)1 << 31), UMT_ERR_INVALID, "warp: too many crops (%d x %d bands)", n, nbands);
   const bool depth_check = (mode & UMT_WARP_NO_DEPTH_CHECK) == 0;
   mode &= ~UMT_WARP_NO_DEPTH_CHECK;
   UMT_REQUIRE(mode == UMT_WARP_CV2_FIXED_POINT || mode == UMT_WARP_FLOAT || mode == UMT_WARP_CV2_FIXED_POINT_F64,
@@ -600,8 +608,8 @@ extern "C" int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offs
               : mode == UMT_WARP_FLOAT         ? (depth_check ? warp_kernel<UMT_WARP_FLOAT> : warp_kernel<UMT_WARP_FLOAT, false>)
               : depth_check                    ? warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64>
                                                : warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64, false>;
-  hipLaunchKernelGGL(kern, dim3(n), dim3(WARP_THREADS), WARP_LDS_BYTES, (hipStream_t)stream, src_images, src_offset,
-                     src_pitch, src_cams, dst_cams, out_h, out_w, out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(n * nbands)), dim3(WARP_THREADS), WARP_LDS_BYTES, (hipStream_t)stream, src_images,
+                     src_offset, src_pitch, src_cams, dst_cams, out_h, out_w, band_h, nbands, out);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
