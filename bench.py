@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 from umetrack_amd import arch, dist as udist, synthetic  # noqa: E402
 from umetrack_amd.lib.common import metric_utils as mu  # noqa: E402
-from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_model  # noqa: E402
+from umetrack_amd.lib.common.hand import hand_model_to, load_generic_hand_model, scaled_hand_model  # noqa: E402
 from umetrack_amd.lib.common.hand_skinning import skin_landmarks  # noqa: E402
 from umetrack_amd.lib.models.model_loader import model_from_state_dict  # noqa: E402
 from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData  # noqa: E402
@@ -114,6 +114,7 @@ class Pipeline:
         self.images = torch.randint(0, 256, (wl.image_bytes,), dtype=torch.uint8, device=device, generator=g)
         hm_m = scaled_hand_model(self.hm, 0.001)
         self.skel = InputSkeletonData(hm_m.joint_rotation_axes.to(device), hm_m.joint_rest_positions.to(device))
+        self.hm_dev = hand_model_to(self.hm, device)     # constant model data resident like the weights: no per-call H2D copies
         # chunks of whole recordings; sample order is [rec][hand][t]
         assert chunk_frames % T == 0
         self.chunk = min(chunk_frames, n_frames) * 2           # samples per chunk
@@ -144,7 +145,7 @@ class Pipeline:
             if self.host_crop_cameras:          # crop cameras precomputed on the host at set-up
                 dst, K, E = self.dst_cams[c0:c1], self.K[c0:c1], self.E[c0:c1]
             else:                               # A0 on the device: FK of 3 poses -> look-at crop cameras -> K, E
-                pts = gpu_crop.crop_points_batched(self.hm, self.gt_angles[s0:s1], self.gt_wrist[s0:s1],
+                pts = gpu_crop.crop_points_batched(self.hm_dev, self.gt_angles[s0:s1], self.gt_wrist[s0:s1],
                                                    self.hand_idx[s0:s1], 63)
                 cams = gpu_crop.gen_crop_cameras_batched(pts, self.rig_cams, self.rig_angles, self.hand_idx[s0:s1],
                                                          forced_views=self.views[s0:s1])
@@ -157,9 +158,9 @@ class Pipeline:
             desc = InputFrameDesc(self.sample_range, self.memory_idx, self.use_memory, self.hand_idx[s0:s1])
             out = self.model.regress_pose_use_skeleton(fd, desc, self.skel, required_rows=cs)
             mark("model")
-            skin_landmarks(self.hm, out.joint_angles, out.wrist_xfs, hand_idx=self.hand_idx[s0:s1], mirror_right=True,
+            skin_landmarks(self.hm_dev, out.joint_angles, out.wrist_xfs, hand_idx=self.hand_idx[s0:s1], mirror_right=True,
                            wrist_translation_scale=1000.0, out=pred[s0:s1])
-            skin_landmarks(self.hm, self.gt_angles[s0:s1], self.gt_wrist[s0:s1], hand_idx=self.hand_idx[s0:s1],
+            skin_landmarks(self.hm_dev, self.gt_angles[s0:s1], self.gt_wrist[s0:s1], hand_idx=self.hand_idx[s0:s1],
                            mirror_right=True, out=gt[s0:s1])
             mark("fk")
         self.partials = mu.metric_partials(self.gt_lm, self.pred_lm, self.valid)

@@ -205,3 +205,17 @@ def test_stream_sharding_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "STREAM OK 2" in out.stdout
+
+
+def test_hand_model_to_keeps_values_and_sets_kernel_dtypes():
+    """hand_model_to: same values, float32 fields, int32 bone indices (what skin_landmarks passes to the kernel)."""
+    import torch
+    from umetrack_amd.lib.common.hand import hand_model_to, load_generic_hand_model
+    hm = load_generic_hand_model()
+    hd = hand_model_to(hm, "cpu")
+    assert hd.landmark_rest_bone_indices.dtype == torch.int32
+    assert torch.equal(hd.landmark_rest_bone_indices.long(), torch.as_tensor(hm.landmark_rest_bone_indices).long())
+    for k in ("joint_rotation_axes", "joint_rest_positions", "landmark_rest_positions", "landmark_rest_bone_weights", "joint_limits"):
+        a, b = getattr(hd, k), torch.as_tensor(getattr(hm, k))
+        assert a.dtype == torch.float32 and a.is_contiguous() and torch.equal(a, b.float())
+    assert hd.hand_scale == hm.hand_scale or hd.hand_scale is hm.hand_scale

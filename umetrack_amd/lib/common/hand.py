@@ -33,6 +33,20 @@ class HandModel(NamedTuple):
     joint_limits: Optional[torch.Tensor] = None
 
 
+def hand_model_to(hand_model: HandModel, device) -> HandModel:
+    """The model with its tensor fields resident on ``device`` in the dtypes the kernels take (float32, bone indices
+    int32), so that `skin_landmarks` / `crop_points_batched` find them in place instead of copying 5 small host tensors
+    per call (pageable host-to-device copies synchronise the stream).  No counterpart in the reference, whose
+    `skin_landmarks` runs where its inputs live."""
+    def move(k, v):
+        if not isinstance(v, torch.Tensor):
+            return v
+        if k == "landmark_rest_bone_indices":
+            return v.to(device=device, dtype=torch.int32).contiguous()
+        return v.to(device=device, dtype=torch.float32 if v.is_floating_point() else v.dtype).contiguous()
+    return HandModel(**{k: move(k, v) for k, v in hand_model._asdict().items()})
+
+
 def load_hand_model_from_dict(d) -> HandModel:
     """lib/tracker/video_pose_data.py:63-72: lists become float tensors, scalars stay."""
     return HandModel(**{k: (torch.Tensor(v) if isinstance(v, list) else v) for k, v in d.items()})

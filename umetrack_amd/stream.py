@@ -57,7 +57,7 @@ class StreamRunner:
 
     def __init__(self, device: torch.device, precision: str = "fp32", chunk_frames: int = 4096,
                  frames_per_recording: int = 64, base_seed: int = 1000, weight_seed: int = 0, rig_seed: int = 0):
-        from .lib.common.hand import load_generic_hand_model, scaled_hand_model
+        from .lib.common.hand import hand_model_to, load_generic_hand_model, scaled_hand_model
         from .lib.models.model_loader import model_from_state_dict
         from .lib.models.umetrack_model import InputSkeletonData
         from .lib.tracker import warp as gpu_warp
@@ -66,6 +66,7 @@ class StreamRunner:
         self.chunk_frames = chunk_frames
         self.base_seed = base_seed
         self.hm = load_generic_hand_model()
+        self.hm_dev = hand_model_to(self.hm, self.dev)     # constant model data resident on the GPU
         self.model = model_from_state_dict(arch.make_synthetic_state(weight_seed)).to(self.dev)
         self.model.precision = precision
         hm_m = scaled_hand_model(self.hm, 0.001)
@@ -135,7 +136,7 @@ class StreamRunner:
         lay = self._chunk_layout(n_frames)
         S, hand = lay["S"], lay["hand"]
         ja, wrist, images = self.generate(chunk, n_frames)
-        pts = gpu_crop.crop_points_batched(self.hm, ja, wrist, hand, 63)
+        pts = gpu_crop.crop_points_batched(self.hm_dev, ja, wrist, hand, 63)
         # the two rig cameras whose optical axis is closest to the hand, in index order (section 8d: exactly 2 views)
         rel = pts[:, :21].mean(dim=1)[:, None, :] - self.rig_pos[None]
         cosang = (rel / rel.norm(dim=2, keepdim=True) * self.rig_axis[None]).sum(-1)
@@ -147,7 +148,7 @@ class StreamRunner:
         fd = InputFrameData(crops, cams.intrinsics.view(-1, 3, 3), cams.extrinsics.view(-1, 4, 4))
         desc = InputFrameDesc(lay["sample_range"], lay["memory_idx"], lay["use_memory"], hand)
         out = self.model.regress_pose_use_skeleton(fd, desc, self.skel, required_rows=S)
-        pred = skin_landmarks(self.hm, out.joint_angles, out.wrist_xfs, hand_idx=hand, mirror_right=True,
+        pred = skin_landmarks(self.hm_dev, out.joint_angles, out.wrist_xfs, hand_idx=hand, mirror_right=True,
                               wrist_translation_scale=1000.0)
         gt = pts[:, :21].contiguous()                      # the tracked pose's landmarks are the ground truth
         ok = (cams.status == 0).all(dim=1)
