@@ -289,6 +289,9 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? UMT_F32_MINB_1TILE : 2)) void 
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch loads ahead of this tap's MFMAs
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
+        // channel groups past the end (cin_s = 80 of the regressor layers: 2 of the last chunk's 4) hold zeros: the
+        // single-tile configuration of the head skips their MFMAs, the backbone layers have none
+        if (TM * TN == 1 && chunk * 4 + c >= c8_total) continue;
         float4 av[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(sA + arow[i][tap] + c * 8);
