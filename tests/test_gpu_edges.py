@@ -165,3 +165,38 @@ def test_fp32_persistent_stage1_kernel_bit_identical_to_halo_kernel(tmp_path):
     img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(77))
     got = np.concatenate([gm.backbone(img[:57].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()])
     assert np.array_equal(got, np.load(out))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs", [1, 37, 256])
+def test_fused_1x1_chains_bit_identical_to_three_launches(bs, monkeypatch):
+    """View fusion (144 -> 108 -> 72 -> 72) and the temporal module (90 -> 90 -> 90 -> 90) run as one kernel each
+    (csrc/conv_chain.hip: operands swapped, a layer's accumulator registers are the next layer's operand).  With
+    UMT_CONV_NOCHAIN=1 (read per model handle at umt_model_create) they run as three conv_igemm_f32 launches.  Same k
+    order and epilogue arithmetic: fused features, temporal output and the memory state left behind must agree bit for
+    bit; bs = 1 and 37 leave the last 32-pixel wave tile ragged (36 and 1332 rows)."""
+    import torch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    g = torch.Generator().manual_seed(100 + bs)
+    n = 2 * bs
+    feats = torch.randn(n, 72, 6, 6, generator=g).cuda()
+    K = torch.tensor([[120.0, 0, 48], [0, 120.0, 48], [0, 0, 1]]).repeat(n, 1, 1)
+    K[:, 0, 0] += torch.rand(n, generator=g) * 20
+    E = torch.eye(4).repeat(n, 1, 1)
+    E[:, :3, 3] = torch.randn(n, 3, generator=g) * 0.05
+    sr = torch.stack([torch.arange(0, n, 2), torch.arange(2, n + 2, 2)], 1)
+    midx = torch.arange(bs)
+
+    def run():
+        gm = model_from_state_dict(arch.make_synthetic_state(9)).to("cuda")
+        fused = gm.fuse_views(feats, K, E, sr)
+        t0 = gm.temporal_step(fused, E[0::2].contiguous(), midx, torch.zeros(bs, dtype=torch.bool), required_rows=bs)
+        t1 = gm.temporal_step(fused * 0.5, E[1::2].contiguous(), midx, torch.ones(bs, dtype=torch.bool), required_rows=bs)
+        gm.check_status()
+        return [x.cpu() for x in (fused, t0, t1)]
+
+    got = run()
+    monkeypatch.setenv("UMT_CONV_NOCHAIN", "1")
+    ref = run()
+    for a, b in zip(got, ref):
+        assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -4,6 +4,7 @@
 #include "../umetrack_amd/csrc/conv_bf16.hip"
 #include "../umetrack_amd/csrc/conv_thin.hip"
 #include "../umetrack_amd/csrc/conv_x3.hip"
+#include "../umetrack_amd/csrc/conv_chain.hip"
 #include <vector>
 #include <stdio.h>
 #include <string.h>

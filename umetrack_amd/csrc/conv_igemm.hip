@@ -548,12 +548,13 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
 
 int conv_thin_prepare_device();
 int conv_x3_prepare_device();
+int conv_chain_prepare_device();
 
 unsigned conv_flags_from_env() {
   static const struct { const char* name; unsigned bit; } kSwitches[] = {
       {"UMT_CONV_NOTHIN", CONV_NO_THIN},         {"UMT_CONV_NOFUSE", CONV_NO_FUSE}, {"UMT_CONV_NOSTREAM128", CONV_NO_STREAM128},
       {"UMT_CONV_NOTHIN_F32", CONV_NO_THIN_F32}, {"UMT_CONV_GATHER", CONV_GATHER},  {"UMT_CONV_NOS2", CONV_NO_S2},
-      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}};
+      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}, {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}};
   unsigned f = 0;
   for (const auto& s : kSwitches)
     if (getenv(s.name)) f |= s.bit;
@@ -565,6 +566,7 @@ int conv_prepare_device() {
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, false>), lds));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, true>), lds));
   UMT_TRY(conv_x3_prepare_device());
+  UMT_TRY(conv_chain_prepare_device());
   return conv_thin_prepare_device();
 }
 

@@ -638,9 +638,13 @@ static int fuse_rows(umt_model* m, const float* feat, const float* K, const floa
                      const HeadWs& w, hipStream_t s) {
   UMT_TRY(launch_fusion_xforms(K, E, sr, n, bs, w.crop_xf, w.sample_xf, w.views, m->status, s));
   UMT_TRY(launch_ftl_concat(feat, w.crop_xf, sr, w.views, n, bs, w.cat, s));
-  UMT_TRY(launch_conv(m->fuse1, w.cat, bs, 6, 6, nullptr, w.f1, s));
-  UMT_TRY(launch_conv(m->fuse2, w.f1, bs, 6, 6, nullptr, w.f2, s));
-  UMT_TRY(launch_conv(m->fuse3, w.f2, bs, 6, 6, nullptr, w.f3, s));
+  if (conv_chain3_applicable(m->fuse1, m->fuse2, m->fuse3)) {
+    UMT_TRY(launch_conv_chain3(m->fuse1, m->fuse2, m->fuse3, w.cat, (int64_t)bs * 36, w.f3, s));
+  } else {
+    UMT_TRY(launch_conv(m->fuse1, w.cat, bs, 6, 6, nullptr, w.f1, s));
+    UMT_TRY(launch_conv(m->fuse2, w.f1, bs, 6, 6, nullptr, w.f2, s));
+    UMT_TRY(launch_conv(m->fuse3, w.f2, bs, 6, 6, nullptr, w.f3, s));
+  }
   UMT_CHECK_HIP(hipMemsetAsync(w.tin, 0, (size_t)bs * 36 * 96 * sizeof(float), s));
   UMT_TRY(launch_ftl_select(w.f3, feat, w.sample_xf, sr, w.views, n, bs, w.tin, 96, 18, s));
   return 0;
@@ -654,9 +658,13 @@ static int temporal_rows(umt_model* m, const float* cam0, const int64_t* midx, c
   if (m->mem_epoch == 0) m->mem_epoch = 1;
   UMT_TRY(launch_temporal_gather(m->mem, m->prev_ext, m->mem_owner, m->mem_epoch, m->mem_rows, cam0, midx, use, bs, w.tin, 96,
                                  w.rel_xf, w.row_of, m->status, s));
-  UMT_TRY(launch_conv(m->temp[0], w.tin, bs, 6, 6, nullptr, w.t1, s));
-  UMT_TRY(launch_conv(m->temp[1], w.t1, bs, 6, 6, nullptr, w.t2, s));
-  UMT_TRY(launch_conv(m->temp[2], w.t2, bs, 6, 6, nullptr, w.t1, s));
+  if (conv_chain3_applicable(m->temp[0], m->temp[1], m->temp[2])) {
+    UMT_TRY(launch_conv_chain3(m->temp[0], m->temp[1], m->temp[2], w.tin, (int64_t)bs * 36, w.t1, s));
+  } else {
+    UMT_TRY(launch_conv(m->temp[0], w.tin, bs, 6, 6, nullptr, w.t1, s));
+    UMT_TRY(launch_conv(m->temp[1], w.t1, bs, 6, 6, nullptr, w.t2, s));
+    UMT_TRY(launch_conv(m->temp[2], w.t2, bs, 6, 6, nullptr, w.t1, s));
+  }
   UMT_TRY(launch_temporal_split(w.t1, 96, m->mem, w.row_of, bs, out_rows, out_cs, s));
   return 0;
 }

@@ -59,6 +59,7 @@ enum : unsigned {
   CONV_GATHER = 16u,        // UMT_CONV_GATHER: every fp32 convolution on the per-tap gather kernel
   CONV_NO_S2 = 32u,         // UMT_CONV_NOS2: no fused stride-2 + down-sample kernel
   CONV_X3_NO_S2 = 64u,      // UMT_X3_NOS2
+  CONV_NO_CHAIN = 256u,     // UMT_CONV_NOCHAIN: the head's 1x1 chains as three conv_igemm_f32 launches instead of conv_chain.hip
   CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
 };
 unsigned conv_flags_from_env();
@@ -109,6 +110,11 @@ struct ConvLayer {
 // conv_igemm.hip
 int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
                 float* out, hipStream_t stream);
+
+// conv_chain.hip: three consecutive 1x1 layers in one kernel (view fusion, temporal module)
+bool conv_chain3_applicable(const ConvLayer& a, const ConvLayer& b, const ConvLayer& c);
+int launch_conv_chain3(const ConvLayer& l0, const ConvLayer& l1, const ConvLayer& l2, const float* in, int64_t rows, float* out,
+                       hipStream_t stream);
 
 // conv1 (3x3 stride 2) of a stage's first block fused with its 1x1 stride-2 down-sample branch (ds may be null)
 bool conv_s2_fused_applicable(const ConvLayer& c1, const ConvLayer* ds, int h, int w);
