@@ -200,3 +200,23 @@ def test_fused_1x1_chains_bit_identical_to_three_launches(bs, monkeypatch):
     ref = run()
     for a, b in zip(got, ref):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_persistent_stride2_kernel_bit_identical_to_one_tile_kernel(monkeypatch):
+    """fp32 mode: the three fused stride-2 + down-sample layers run on the persistent kernel conv3x3s2p_ds_f32 (a workgroup
+    walks its XCD's tiles and fetches the next tile's input under the epilogue); with UMT_CONV_NOS2P=1 (read per model handle)
+    on conv3x3s2_ds_f32, one tile per workgroup.  Same tiles, k order and epilogue: features must agree bit for bit.
+    3 crops leave most workgroups without a tile on the last layer, 131 make the last tiles ragged."""
+    import torch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(78)).cuda()
+
+    def run():
+        gm = model_from_state_dict(arch.make_synthetic_state(6)).to("cuda")
+        return torch.cat([gm.backbone(img[:3]), gm.backbone(img)]).cpu()
+
+    got = run()
+    monkeypatch.setenv("UMT_CONV_NOS2P", "1")
+    ref = run()
+    assert torch.isfinite(got).all() and torch.equal(got, ref)

@@ -253,7 +253,7 @@ int main(int argc, char** argv) {
   }
   // fused stride-2 conv1 + down-sample vs the two separate launches
   if (strcmp(which, "bf16")) {
-    const int cfgs[2][3] = {{64, 128, 24}, {128, 256, 12}};
+    const int cfgs[3][3] = {{32, 64, 48}, {64, 128, 24}, {128, 256, 12}};
     for (auto& cf : cfgs) {
       const int cin = cf[0], cout = cf[1], hw = cf[2], ho = hw / 2;
       ConvLayer C, D;
@@ -293,9 +293,25 @@ int main(int argc, char** argv) {
       hipEventRecord(e0, 0);
       for (int i = 0; i < 5; ++i) launch_conv_s2_fused(C, &D, in, n, hw, hw, o2, d2, 0);
       hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_fused, e0, e1v);
+      // the one-tile-per-workgroup fused kernel (CONV_NO_S2P) against the persistent one: must agree bit for bit
+      ConvLayer Cold = C;
+      Cold.flags |= CONV_NO_S2P;
+      hipMemset(o1, 0xff, out_n * 4); hipMemset(d1, 0xff, out_n * 4);
+      if (launch_conv_s2_fused(Cold, &D, in, n, hw, hw, o1, d1, 0)) return 1;
+      hipDeviceSynchronize();
+      size_t bad_p = 0;
+      hipMemcpy(a.data(), o1, out_n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o2, out_n * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < out_n; ++i) bad_p += memcmp(&a[i], &b[i], 4) != 0;
+      hipMemcpy(a.data(), d1, out_n * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), d2, out_n * 4, hipMemcpyDeviceToHost);
+      for (size_t i = 0; i < out_n; ++i) bad_p += memcmp(&a[i], &b[i], 4) != 0;
+      float ms_old;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < 5; ++i) launch_conv_s2_fused(Cold, &D, in, n, hw, hw, o1, d1, 0);
+      hipEventRecord(e1v, 0); hipEventSynchronize(e1v); hipEventElapsedTime(&ms_old, e0, e1v);
       const double fl = 2.0 * cin * cout * 10 * ho * ho * n;
-      printf("s2+ds %3d->%3d hw %2d: conv1 max|diff| %.3g (max|x| %.3g), ds differing words %zu; separate %.1f us, fused %.1f us (%.1f TF)\n",
-             cin, cout, hw, e1, mx, bad, ms_sep / 5 * 1e3, ms_fused / 5 * 1e3, fl / (ms_fused / 5) / 1e9);
+      printf("s2+ds %3d->%3d hw %2d: conv1 max|diff| %.3g (max|x| %.3g), ds differing words %zu; separate %.1f us, fused %.1f us (%.1f TF); "
+             "one-tile kernel %.1f us, words differing from it %zu\n",
+             cin, cout, hw, e1, mx, bad, ms_sep / 5 * 1e3, ms_fused / 5 * 1e3, fl / (ms_fused / 5) / 1e9, ms_old / 5 * 1e3, bad_p);
       hipFree(in); hipFree(o1); hipFree(o2); hipFree(d1); hipFree(d2); hipFree(w); hipFree(wd); hipFree(vec);
     }
   }

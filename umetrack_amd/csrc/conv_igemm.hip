@@ -485,6 +485,197 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent form of conv3x3s2_ds_f32 (round 2).  Same tile (64 output pixels), same staged input range, same k order
+// (32-channel chunk, tap, 8-channel group, element; the down-sample product of the centre tap in its own accumulators),
+// same epilogue: bit-identical results.  What changes is what happens BETWEEN tiles and chunks:
+//   * a workgroup walks a contiguous run of tiles of its XCD (neighbouring workgroups share their overlapping input
+//     rows through that XCD's L2) and fetches the NEXT work item's input range - the next chunk or the next tile's first
+//     chunk - into registers while the current chunk's MFMAs run.  The 32 -> 64 layer has a single chunk per tile: in
+//     the one-tile-per-workgroup kernel every workgroup exposed its own 57 KB fetch (89 TFLOP/s);
+//   * the weight stream keeps the whole-tap double buffer (a ring of single (tap, channel group) entries three ahead was
+//     1.2-2x SLOWER: a fragment requested after the input-range fetch waits for all of it in the in-order load counter,
+//     and three entries of MFMAs do not cover an HBM round trip; a whole tap's 16 MFMAs nearly do).
+#ifndef UMT_S2P_ATAP
+#define UMT_S2P_ATAP 0
+#endif
+template <int TN, bool DS>
+__global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int tiles_m, int tiles_n) {
+  const ConvArgs& a = g.c1;
+  constexpr int BM = S2_BM, BN = 2 * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) float sA[];   // rows x LDA + one zero row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+  const int c8_total = a.cin_s >> 3;
+  const int nchunks = (a.cin_s + KC - 1) / KC;
+  const int zrow = S2_ROWS_MAX;
+
+  // tiles [t_lo, t_hi) of this workgroup's XCD, dealt round-robin to the XCD's workgroups
+  const int ntiles = tiles_m * tiles_n;
+  const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = (gridDim.x + 7 - xcd) >> 3;
+  const int t_lo = (int)((int64_t)ntiles * xcd / 8), t_hi = (int)((int64_t)ntiles * (xcd + 1) / 8);
+
+  auto centre = [&](int m) {
+    const int Rr = div_magic32(m, Wo, a.mg_w), xo = m - Rr * Wo;      // for this kernel mg_w / mg_hw divide by Wo / Ho
+    return 2 * W * Rr + 2 * xo;
+  };
+  struct Tile { int m0, n0, g0, rows; };
+  auto tile_of = [&](int t) {
+    Tile T;
+    const int tm = t / tiles_n;
+    T.m0 = tm * BM;
+    T.n0 = (t - tm * tiles_n) * BN;
+    const int m_last = min(T.m0 + BM, a.M) - 1;
+    T.g0 = centre(T.m0) - W - 1;
+    T.rows = centre(m_last) + W + 1 - T.g0 + 1;
+    return T;
+  };
+
+  if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + zrow * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(DS ? g.ds_w : a.w), 0, 0x7fffffff, 0x00020000);
+  const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 4 * sizeof(float));
+  const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float);
+  const size_t w_tap = (size_t)c8_total * w_c8;
+
+  // weight fragments: whole-tap double buffer as in conv3x3s2_ds_f32 (a tap's 16 x TN MFMAs cover the next tap's loads
+  // even when they queue behind the input-range fetch in the in-order load counter; a finer ring does not)
+  float4 bcur[4][TN], bnext[4][TN], bds[4][TN];
+  auto load_b = [&](float4 (&dst)[4][TN], __amdgpu_buffer_rsrc_t blk, int tap, int chunk, int voff) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int c8 = min(chunk * 4 + c, c8_total - 1);
+      const int soff = (int)(tap * w_tap + c8 * w_c8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4v v = __builtin_bit_cast(f32x4v, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(blk, voff + j * 512, soff, 0));
+        dst[c][j] = make_float4(v.x, v.y, v.z, v.w);
+      }
+    }
+  };
+
+  constexpr int NLD = S2_ROWS_MAX / 32;                  // float4 slots per thread
+  float4 areg[NLD];
+  unsigned aok = 0;
+  int arows = 0;                                         // rows of the range held in areg
+  auto load_a = [&](const Tile& T, int chunk) {
+    const int c0 = chunk * KC;
+    aok = 0;
+    arows = T.rows;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 3, q = idx & 7;
+      const int gp = T.g0 + r;
+      const bool ok = r < T.rows && gp >= 0 && (c0 + 4 * q) < a.cin_s;      // gp < n*H*W follows from r < rows
+      const size_t off = ok ? (size_t)gp * a.cin_s + c0 + 4 * q : 0;
+      areg[k] = *reinterpret_cast<const float4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+
+  int t = t_lo + wg_in_xcd;
+  if (t >= t_hi) return;
+  Tile cur = tile_of(t);
+  load_a(cur, 0);
+  int voff = (int)(cur.n0 * 16 + wlane_off);
+  load_b(bcur, wblock, 0, 0, voff);
+
+  for (; t < t_hi; t += wgs_per_xcd) {
+    const bool has_next = t + wgs_per_xcd < t_hi;
+    Tile nxt = cur;
+    if (has_next) nxt = tile_of(t + wgs_per_xcd);
+    const int voff_next = (int)(nxt.n0 * 16 + wlane_off);
+
+    int arow[9];
+    {
+      const int m = cur.m0 + wm * 32 + li;
+      const bool live = m < a.M;
+      const int mm = live ? m : cur.m0;
+      const int Rr = div_magic32(mm, Wo, a.mg_w), xo = mm - Rr * Wo, yo = Rr - div_magic32(Rr, Ho, a.mg_hw) * Ho;
+      const int base = 2 * W * Rr + 2 * xo - cur.g0;            // LDS row of the centre tap
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
+          const bool ok = live && yy >= 0 && yy < a.H && xx >= 0 && xx < W;
+          arow[ky * 3 + kx] = (ok ? base + (ky - 1) * W + (kx - 1) : zrow) * LDA + 4 * lh;
+        }
+    }
+    f32x16 acc[1][TN], accd[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[0][j][r] = 0.f; accd[0][j][r] = 0.f; }
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k;
+        float4 v = areg[k];
+        if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((idx >> 3) < arows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
+      }
+      __syncthreads();
+      const bool last_chunk = chunk + 1 == nchunks;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 8) load_b(bnext, wblock, tap + 1, chunk, voff);
+        else if (!last_chunk) load_b(bnext, wblock, 0, chunk + 1, voff);
+        else if (has_next) load_b(bnext, wblock, 0, 0, voff_next);
+        if (DS && tap == 3) load_b(bds, dblock, 0, chunk, voff);
+        if (tap == UMT_S2P_ATAP && !last_chunk) load_a(cur, chunk + 1);      // the next chunk's input range
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 av = *reinterpret_cast<const float4*>(sA + arow[tap] + c * 8);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bcur[c][j].x, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bcur[c][j].y, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bcur[c][j].z, acc[0][j], 0, 0, 0);
+            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bcur[c][j].w, acc[0][j], 0, 0, 0);
+          }
+          if (DS && tap == 4) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bds[c][j].x, accd[0][j], 0, 0, 0);
+              accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bds[c][j].y, accd[0][j], 0, 0, 0);
+              accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bds[c][j].z, accd[0][j], 0, 0, 0);
+              accd[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bds[c][j].w, accd[0][j], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bcur[c][j] = bnext[c][j];
+      }
+      __syncthreads();
+    }
+    // the next tile's input range is requested here, behind the last weight load of this tile (a weight fragment requested
+    // after it would wait for all of it in the in-order load counter), and arrives under the two epilogues
+    if (has_next) load_a(nxt, 0);
+
+    float* patch = sA + wave * 32 * LDA;
+    epilogue<1, TN, false>(acc, patch, lane, cur.m0 + wm * 32, cur.n0 + wn * TN * 32, a);
+    if (DS) {
+      ConvArgs d = a;
+      d.bias = g.ds_bias; d.scale = g.ds_scale; d.shift = g.ds_shift; d.out = g.ds_out; d.relu = 0; d.residual = nullptr;
+      epilogue<1, TN, false>(accd, patch, lane, cur.m0 + wm * 32, cur.n0 + wn * TN * 32, d);
+    }
+    __syncthreads();          // the patches alias the staging area the next tile is about to fill
+    cur = nxt;
+    voff = voff_next;
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_halo(const ConvArgs& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -554,7 +745,7 @@ unsigned conv_flags_from_env() {
   static const struct { const char* name; unsigned bit; } kSwitches[] = {
       {"UMT_CONV_NOTHIN", CONV_NO_THIN},         {"UMT_CONV_NOFUSE", CONV_NO_FUSE}, {"UMT_CONV_NOSTREAM128", CONV_NO_STREAM128},
       {"UMT_CONV_NOTHIN_F32", CONV_NO_THIN_F32}, {"UMT_CONV_GATHER", CONV_GATHER},  {"UMT_CONV_NOS2", CONV_NO_S2},
-      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}, {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}};
+      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}, {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}, {"UMT_CONV_NOS2P", CONV_NO_S2P}};
   unsigned f = 0;
   for (const auto& s : kSwitches)
     if (getenv(s.name)) f |= s.bit;
@@ -565,6 +756,10 @@ int conv_prepare_device() {
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, false>), lds));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, true>), lds));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<1, false>), lds));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<1, true>), lds));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, false>), lds));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, true>), lds));
   UMT_TRY(conv_x3_prepare_device());
   UMT_TRY(conv_chain_prepare_device());
   return conv_thin_prepare_device();
@@ -599,6 +794,18 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
   // 64 x 64 workgroup tiles (one 32x32 tile per wave and convolution): wider cout tiles would need the
   // weight double buffers of both convolutions for two tiles and spill
+  if (!(c1.flags & CONV_NO_S2P)) {
+    // persistent kernel: 64 x 128 tiles where cout allows, two workgroups per CU walking their XCD's tiles
+    const bool wide = false;      // TN = 2 needs both whole-tap buffers for two tiles: spills (measured 2x slower)
+    const int tiles_m = (a.M + S2_BM - 1) / S2_BM, tiles_n = c1.cout_w / (wide ? 128 : 64);
+    const int64_t ntiles = (int64_t)tiles_m * tiles_n;
+    const unsigned wgs = (unsigned)(ntiles < 512 ? (ntiles + 7) / 8 * 8 : 512);
+    void (*pk)(ConvS2Args, int, int) = wide ? (ds ? conv3x3s2p_ds_f32<2, true> : conv3x3s2p_ds_f32<2, false>)
+                                            : (ds ? conv3x3s2p_ds_f32<1, true> : conv3x3s2p_ds_f32<1, false>);
+    hipLaunchKernelGGL(pk, dim3(wgs), dim3(256), lds, stream, g, tiles_m, tiles_n);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 grid((a.M + S2_BM - 1) / S2_BM, c1.cout_w / 64);
   void (*kern)(ConvS2Args) = ds ? conv3x3s2_ds_f32<1, true> : conv3x3s2_ds_f32<1, false>;
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
