@@ -132,7 +132,10 @@ int umt_crop_cameras(const float* points, int n_points, const double* cameras, c
  * src_pitch[k] (bytes) - this is how a 4-view-wide frame is addressed (video_pose_data.py:123-125).
  * src_cams  dev float64 (n,30): w,h,fx,fy,cx,cy,k1,k2,k3,k4,p1,p2,k5,k6, cam_to_world 4x4 row-major
  * dst_cams  dev float64 (n,20): fx,fy,cx,cy, cam_to_world 4x4 row-major (96x96 pinhole crop cameras)
- * out       dev float32 (n,out_h,out_w), values in [0,1]                                            */
+ * out       dev float32 (n,out_h,out_w), values in [0,1]; out_w <= 3072, any out_h (a workgroup takes a band of rows)
+ * The kernel copies the source rectangle of a band with aligned 4-byte loads: it may read up to 3 bytes before an image
+ * row's first byte and up to 3 bytes past its last byte (never outside the 4-byte words those bytes lie in), so
+ * src_images must be an allocation whose size is a multiple of 4 bytes (every hipMalloc'd buffer is).           */
 int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offset, const int32_t* src_pitch,
                    const double* src_cams, const double* dst_cams, int n, int out_h, int out_w,
                    int mode, float* out, void* stream);
