@@ -306,7 +306,7 @@ def test_warp_fast_maps_bit_identical_to_float64_maps():
     assert torch.equal(a, b), int((a != b).sum())
 
 
-@pytest.mark.parametrize("out_hw", [(96, 96), (45, 45), (64, 80), (33, 7)])
+@pytest.mark.parametrize("out_hw", [(96, 96), (45, 45), (64, 80), (33, 7), (120, 200), (70, 96)])
 def test_warp_other_crop_sizes(out_hw):
     """Crop sizes whose pixel count is not a multiple of 4 (scalar output stores, pixel groups that wrap over a
     row end) and non-square crops: mode 0 == mode 2 bit for bit, and both follow the oracle remap on the oracle's
