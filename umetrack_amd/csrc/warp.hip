@@ -108,7 +108,8 @@ __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v,
 // MEASURED, not assumed: the float64 map is also evaluated at the midpoints of the cell's four edges (where the error of the
 // 1-D cubic along that edge peaks; the error of the tensor-product interpolant inside the cell is the sum of the two 1-D
 // errors to leading order), and a pixel's interpolated coordinate is accepted only when its distance to the nearest 1/32-px
-// rounding boundary exceeds twice (larger horizontal-edge error + larger vertical-edge error) plus the float32 arithmetic bound.  Nodes that are not regular (behind or within 1.1 degrees of the source camera's
+// rounding boundary exceeds twice (1.25 x largest horizontal-edge error + largest vertical-edge error over the stencil's grid
+// lines) plus the float32 arithmetic bound.  Nodes that are not regular (behind or within 1.1 degrees of the source camera's
 // z = 0 plane, not finite, out of range) are NaN and make every cell they touch undecided; undecided pixels go to the
 // float64 queue like those of the per-pixel float32 map.  All 16 nodes regular implies the cell is: with a shared centre the
 // set {z > 0.02 |p|} is a circular cone of rays, whose section with the crop's image plane is convex.
@@ -288,14 +289,22 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
       __syncthreads();
       if (tid < ICX * ICY) {
         const int cj = tid / ICX, ci = tid - cj * ICX;
-        const float eh = nan_max(errs[cj * ICX + ci], errs[(cj + 1) * ICX + ci]);
-        const float ev = nan_max(errs[I_HE + cj * (ICX + 1) + ci], errs[I_HE + cj * (ICX + 1) + ci + 1]);
+        // f - Iu Iv f = (f - Iv f) + Iv (f - Iu f): the second term is the v-interpolant (Lebesgue constant 1.25) of the
+        // u-errors on the stencil's FOUR node rows, so the horizontal-edge error is taken over all measured rows of the
+        // stencil (grid rows cj-1 .. cj+2 of this band), and likewise the vertical-edge error over its columns
+        float eh = 0.f, ev = 0.f;
+#pragma unroll
+        for (int d = -1; d <= 2; ++d) {
+          const int r = min(max(cj + d, 0), ICY), c = min(max(ci + d, 0), ICX);
+          eh = nan_max(eh, errs[r * ICX + ci]);
+          ev = nan_max(ev, errs[I_HE + cj * (ICX + 1) + c]);
+        }
         // float32 side of the bound, worst case, with u = 2^-24 and R = relmax (largest node value relative to the centre
         // node): a node is rounded to float32 (u R); the column combination is 4 roundings of partial sums <= 1.25 R (the
         // cubic weights sum to <= 1.25 in absolute value), 3 u relative error of each weight, and the node errors: 10 u R;
         // the row combination adds 4 roundings of sums <= 1.5625 R, the weights again and 1.25 x the column error:
         // 23.5 u R = 1.4e-6 R in all, plus the final addition (u (R + 1))
-        cell_e[tid] = 2.0f * (eh + ev) + 1.6e-6f * __int_as_float(relmax_bits) + 0.001f;
+        cell_e[tid] = 2.0f * (1.25f * eh + ev) + 1.6e-6f * __int_as_float(relmax_bits) + 0.001f;
       }
       __syncthreads();
       WSTAMP(2);
