@@ -306,6 +306,42 @@ def test_warp_fast_maps_bit_identical_to_float64_maps():
     assert torch.equal(a, b), int((a != b).sum())
 
 
+def test_warp_interpolated_map_adversarial_cameras():
+    """The interpolated map must hand every pixel it cannot decide to the float64 queue, whatever the camera: crop
+    cameras from 5 to 88 degrees off the source axis (up to and across the z = 0 plane inside the crop), crop focal lengths
+    from 25 px (100-degree crops, strongly curved maps) to 500 px, distortion coefficients up to 40x the bench's (radial
+    polynomials that fold back), rolled crops.  3072 crops of one noise image (any 1/32-px difference changes the
+    sample), MODE_CV2 == MODE_CV2_F64 bit for bit."""
+    from umetrack_amd.lib.tracker import warp as w
+    rng = np.random.default_rng(2024)
+    n, sw, sh = 3072, 640, 480
+    base = np.array([-0.03, 0.01, -0.004, 0.0006, 2e-4, -1e-4, -3e-5, 1e-5])      # k1..k4, p1, p2, k5, k6
+    src_c2w = np.eye(4)
+    src_c2w[:3, 3] = (10.0, -20.0, 5.0)
+    S, D = [], []
+    for i in range(n):
+        coeffs = base * rng.uniform(-40.0, 40.0, size=8) * (rng.random() < 0.7)
+        S.append(w.pack_fisheye(sw, sh, (rng.uniform(200, 320),) * 2, (rng.uniform(280, 360), rng.uniform(200, 280)),
+                                coeffs, src_c2w))
+        tilt, az, roll = np.deg2rad(rng.uniform(5, 88)), rng.uniform(0, 2 * np.pi), rng.uniform(0, 2 * np.pi)
+        z = np.array([np.sin(tilt) * np.cos(az), np.sin(tilt) * np.sin(az), np.cos(tilt)])
+        x = np.cross([0.0, 0.0, 1.0], z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        x, y = np.cos(roll) * x + np.sin(roll) * y, -np.sin(roll) * x + np.cos(roll) * y
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2] = x, y, z
+        c2w[:3, 3] = src_c2w[:3, 3]
+        f = float(np.exp(rng.uniform(np.log(25.0), np.log(500.0))))
+        D.append(w.pack_pinhole((f, f * rng.uniform(0.9, 1.1)), (47.5 + rng.uniform(-10, 10), 47.5 + rng.uniform(-10, 10)), c2w))
+    img = torch.from_numpy(rng.integers(0, 256, size=(sw * sh + 16,), dtype=np.uint8)).cuda()
+    args = (img, [0] * n, [sw] * n, np.stack(S), np.stack(D))
+    a = w.warp_crops(*args, mode=w.MODE_CV2)
+    b = w.warp_crops(*args, mode=w.MODE_CV2_F64)
+    assert torch.equal(a, b), int((a != b).sum())
+    assert float((a > 0).float().mean()) > 0.2            # the crops do see the image
+
+
 @pytest.mark.parametrize("out_hw", [(96, 96), (45, 45), (64, 80), (33, 7), (120, 200), (70, 96)])
 def test_warp_other_crop_sizes(out_hw):
     """Crop sizes whose pixel count is not a multiple of 4 (scalar output stores, pixel groups that wrap over a
