@@ -344,9 +344,9 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
             const float tx = t.x, ty = t.y;
             const float rx = rintf(tx), ry = rintf(ty);
             const float ax = fabsf((float)irx + tx), ay = fabsf((float)iry + ty);
-            // the reference rounds float32(coordinate) * 32: that cast moves the value by up to 2^-24 of its magnitude
+            // the reference rounds float32(coordinate) * 32: that cast moves the value by up to 2^-24 = 5.96e-8 of its magnitude
             // (bitwise: a short-circuit chain becomes four nested branches per pixel)
-            const bool ok = (int)((0.5f - fabsf(tx - rx)) > eb + 2.4e-7f * ax) & (int)((0.5f - fabsf(ty - ry)) > eb + 2.4e-7f * ay) &
+            const bool ok = (int)((0.5f - fabsf(tx - rx)) > eb + 6.2e-8f * ax) & (int)((0.5f - fabsf(ty - ry)) > eb + 6.2e-8f * ay) &
                             (int)(ax < 960000.f) & (int)(ay < 960000.f);
             sxs[i] = irx + (int)rx;                 // replaced by the queue position below when not accepted
             sys[i] = iry + (int)ry;
