@@ -325,6 +325,15 @@ def stream_main(args, rank, world, dev):
         "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa, "n_valid": fin.n_valid, "n_total": fin.n_total}))
 
 
+def progress(rank, msg):
+    """One line on stderr per phase (every rank): a silent multi-minute run looks hung to a watchdog, and a real hang then
+    names its phase."""
+    print(f"[bench rank {rank} +{time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,12 +373,15 @@ def main():
     if args.stream_frames > 0:
         return stream_main(args, rank, world, dev)
 
+    progress(rank, f"world {world}, device {dev}: building the synthetic workload")
     pipe = Pipeline(args.frames, args.frames_per_recording, args.chunk_frames, seed=rank, device=dev,
                     precision=args.precision, host_crop_cameras=args.host_crop_cameras)
+    progress(rank, f"{args.warmup} warm-up step(s)")
     for _ in range(args.warmup):
         pipe.step()
     torch.cuda.synchronize()
     udist.barrier()
+    progress(rank, f"timing {args.steps} step(s)")
     pipe.model.timing_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -378,6 +390,7 @@ def main():
     torch.cuda.synchronize()
     udist.barrier()
     elapsed = udist.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    progress(rank, f"timed region done: {elapsed / args.steps * 1e3:.2f} ms per step (max over ranks)")
     bb_ms, fwd_ms, calls = pipe.model.timing_read()
     pipe.model.timing_enable(False)
     fin = mu.finalize_partials(pipe.partials)
@@ -407,6 +420,7 @@ def main():
     # side measurements (rank 0's GPU only, no collective in them; never `value`): the same step in the two other
     # backbone modes, 1 warm-up + 2 timed steps each, backbone time from the library's HIP events
     def side_mode(precision, peak, note):
+        progress(rank, f"side measurement: {precision}")
         pipe.model.precision = precision
         pipe.step()
         torch.cuda.synchronize()
@@ -444,6 +458,7 @@ def main():
 
     # per-launch view of the backbone (outside the timed region: the library records a HIP event between every two
     # launches, which costs a little): one more step in the headline precision
+    progress(rank, "per-launch and per-stage steps, recurrent mode")
     pipe.model.layer_timing_enable(True)
     pipe.step()
     layer_rows = pipe.model.layer_timing_read()
@@ -530,6 +545,7 @@ def main():
                       "note": f"{pipe.wl.n_rec} recordings x {pipe.wl.T} frames in lock-step, use_memory=True after "
                               "frame 0, rank 0 only, 1 timed pass", "mpjpe_mm": rec_fin.mpjpe},
     }
+    progress(rank, "host-to-device copy measurements")
     if not args.no_pcie:
         rate = h2d_rate_gbs(dev)
         frame_bytes = pipe.wl.image_bytes
@@ -567,6 +583,7 @@ def main():
                     "copy stream beside the previous step's kernels; bound by max(step, copy)"}
         del host, bufs
     if args.cpu_hands > 0:
+        progress(rank, f"CPU oracle baseline on {args.cpu_hands} hands (about 12 s)")
         base, cpu_pred, cpu_mpjpe = cpu_baseline(pipe, args.cpu_hands)
         line["cpu_baseline"] = base
         n = cpu_pred.shape[0]
