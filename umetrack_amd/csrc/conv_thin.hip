@@ -822,7 +822,8 @@ constexpr int FB_OPIX = FB_R * FB_W;                       // 384 output pixels
 constexpr int FB_XBYTES = (FB_XPIX + 1) * T_LDH * 2;       // + the all-zero row
 constexpr int FB_TBYTES = (FB_TPIX + 1) * T_LDH * 2;
 constexpr int FB_WBYTES = 9 * 2 * 2 * 32 * 16;             // one packed weight tensor
-constexpr int FB_LDS = FB_XBYTES + FB_TBYTES + 2 * FB_WBYTES;
+constexpr int FB_CBYTES = 6 * 32 * 4;                     // bias/scale/shift of both layers
+constexpr int FB_LDS = FB_XBYTES + FB_TBYTES + 2 * FB_WBYTES + FB_CBYTES;
 static_assert(FB_LDS <= 160 * 1024, "block32_fused_bf16: LDS budget");
 
 struct FusedBlockArgs {
@@ -835,6 +836,57 @@ struct FusedBlockArgs {
   int ntiles;              // n * 6
 };
 
+// The 18 k-steps (tap, 16-channel group) of one 3x3 convolution on one or two 32-pixel tiles, all three operand
+// fragments (weights, pixels of tile 0, pixels of tile 1) read from LDS FB_AHEAD steps before the MFMAs that use them and
+// pinned there: read in the step that uses them, every MFMA waited a full LDS round trip (matrix pipe 29 % busy).
+// (acc + bias) * scale + shift on four consecutive channels, as two packed adds and two packed fused multiply-adds (each
+// component rounds exactly as the scalar add + fma the other bf16 kernels use); kc -> this lane's bias quad in LDS, the
+// scale and shift quads follow 32 and 64 floats on (read where they are used: held in registers across the MFMAs they cost
+// 48 registers and no time)
+__device__ __forceinline__ void fb_bn4(const float* kc, float a0, float a1, float a2, float a3, float& v0, float& v1, float& v2,
+                                       float& v3) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const float4 cb = *reinterpret_cast<const float4*>(kc), cs = *reinterpret_cast<const float4*>(kc + 32),
+               ch = *reinterpret_cast<const float4*>(kc + 64);
+  const f32x2 lo = __builtin_elementwise_fma((f32x2){a0, a1} + (f32x2){cb.x, cb.y}, (f32x2){cs.x, cs.y}, (f32x2){ch.x, ch.y});
+  const f32x2 hi = __builtin_elementwise_fma((f32x2){a2, a3} + (f32x2){cb.z, cb.w}, (f32x2){cs.z, cs.w}, (f32x2){ch.z, ch.w});
+  v0 = lo.x; v1 = lo.y; v2 = hi.x; v3 = hi.y;
+}
+
+#ifndef FB_AHEAD
+#define FB_AHEAD 2
+#endif
+template <bool TWO>
+__device__ __forceinline__ void fb_taps(const unsigned char* wbase, const unsigned char* act, const int (&arow)[2][9],
+                                        f32x16 (&acc)[2]) {
+  constexpr int NS = 18, D = FB_AHEAD;
+  uint4 bw[D + 1], r0[D + 1], r1[D + 1];
+  auto rd = [&](int slot, int st) {            // st = tap * 2 + c
+    bw[slot] = *reinterpret_cast<const uint4*>(wbase + st * 1024);
+    r0[slot] = *reinterpret_cast<const uint4*>(act + arow[0][st >> 1] + (st & 1) * 32);
+    if (TWO) r1[slot] = *reinterpret_cast<const uint4*>(act + arow[1][st >> 1] + (st & 1) * 32);
+  };
+#pragma unroll
+  for (int st = 0; st < D; ++st) rd(st, st);
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st + D < NS) rd((st + D) % (D + 1), st + D);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[st % (D + 1)]),
+                                                     __builtin_bit_cast(bf16x8, r0[st % (D + 1)]), acc[0], 0, 0, 0);
+    if (TWO)
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw[st % (D + 1)]),
+                                                       __builtin_bit_cast(bf16x8, r1[st % (D + 1)]), acc[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+#ifdef UMT_FB_STAMP      // diagnostic builds only: phase time stamps of workgroup 3's second tile
+__device__ unsigned long long g_fbstamp[16];
+#define FBSTAMP(i) do { if (blockIdx.x == 3 && threadIdx.x == 0 && T == first_T + tstep) g_fbstamp[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FBSTAMP(i) do {} while (0)
+#endif
 __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
   constexpr int NLD = (FB_XPIX * 4 + 511) / 512;      // 5 uint4 per thread for one input range
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -843,8 +895,13 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned char* sW1 = smem_b + FB_XBYTES + FB_TBYTES;
   unsigned char* sW2 = sW1 + FB_WBYTES;
+  float* sK = reinterpret_cast<float*>(sW2 + FB_WBYTES);     // [bias1 | scale1 | shift1 | bias2 | scale2 | shift2] x 32
   const int li = lane & 31, lh = lane >> 5;
 
+  if (tid < 32) {
+    sK[tid] = a.bias1[tid]; sK[32 + tid] = a.scale1[tid]; sK[64 + tid] = a.shift1[tid];
+    sK[96 + tid] = a.bias2[tid]; sK[128 + tid] = a.scale2[tid]; sK[160 + tid] = a.shift2[tid];
+  }
   for (int i = tid; i < FB_WBYTES / 16; i += 512) {
     *reinterpret_cast<uint4*>(sW1 + 16 * i) = reinterpret_cast<const uint4*>(a.w1)[i];
     *reinterpret_cast<uint4*>(sW2 + 16 * i) = reinterpret_cast<const uint4*>(a.w2)[i];
@@ -891,9 +948,12 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
   }
   __syncthreads();
 
+  const int first_T = T;
+  (void)first_T;
   for (; T < tend; T += tstep) {
     const int img = T / (FB_H / FB_R), y0 = (T - img * (FB_H / FB_R)) * FB_R;
     const bool has_next = T + tstep < tend;
+    FBSTAMP(0);
     if (has_next) load_x(T + tstep);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -902,13 +962,7 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
     // the other way round), so the accumulator is t TRANSPOSED: a lane owns one pixel and the 16 channels
     // 8g + 4*lh + e.  Its BN + ReLU result goes to the pixel's LDS row as four 8-byte stores - no transposing patch.
     {
-      float4 pb[4], ps[4], ph[4];       // constants of the lane's channels, re-read per phase (registers are scarce)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        pb[g] = *reinterpret_cast<const float4*>(a.bias1 + 8 * g + 4 * lh);
-        ps[g] = *reinterpret_cast<const float4*>(a.scale1 + 8 * g + 4 * lh);
-        ph[g] = *reinterpret_cast<const float4*>(a.shift1 + 8 * g + 4 * lh);
-      }
+      const float* kc = sK + 4 * lh;     // constants of the lane's channels: read from LDS where they are used
       const int kt[2] = {wave, wave + 8};
       const bool two = kt[1] < FB_TPIX / 32;
       int arow[2][9];
@@ -931,21 +985,12 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       auto taps1 = [&](auto twoc) {        // two straight-line bodies: a branch inside the tap loop would pin the schedule
         constexpr bool TWO = decltype(twoc)::value;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const uint4 bw = *reinterpret_cast<const uint4*>(sW1 + boff + (tap * 2 + c) * 1024);
-            const uint4 r0 = *reinterpret_cast<const uint4*>(sX + arow[0][tap] + c * 32);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r0), acc[0], 0, 0, 0);
-            if (TWO) {
-              const uint4 r1 = *reinterpret_cast<const uint4*>(sX + arow[1][tap] + c * 32);
-              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r1), acc[1], 0, 0, 0);
-            }
-          }
+        fb_taps<TWO>(sW1 + boff, sX, arow, acc);
       };
+      FBSTAMP(1);
       if (two) taps1(std::true_type{});
       else taps1(std::false_type{});
+      FBSTAMP(2);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (i == 1 && !two) break;
@@ -954,10 +999,8 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
         const bool pad = yt < 0 || yt >= FB_H;           // conv2's zero padding above and below the image
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float v0 = (acc[i][4 * g + 0] + pb[g].x) * ps[g].x + ph[g].x;
-          float v1 = (acc[i][4 * g + 1] + pb[g].y) * ps[g].y + ph[g].y;
-          float v2 = (acc[i][4 * g + 2] + pb[g].z) * ps[g].z + ph[g].z;
-          float v3 = (acc[i][4 * g + 3] + pb[g].w) * ps[g].w + ph[g].w;
+          float v0, v1, v2, v3;
+          fb_bn4(kc + 8 * g, acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], v0, v1, v2, v3);
           v0 = thin_relu(v0); v1 = thin_relu(v1); v2 = thin_relu(v2); v3 = thin_relu(v3);
           uint2 o = make_uint2(thin_pack_bf16x2(v0, v1), thin_pack_bf16x2(v2, v3));
           if (pad) o = make_uint2(0, 0);
@@ -965,19 +1008,15 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
         }
       }
     }
+    FBSTAMP(3);
     __syncthreads();
+    FBSTAMP(4);
 
     // ---- conv2: 12 tiles of 32 output pixels; wave w takes (w+1)%8 and, for four of the waves, that + 8 (wave 7 had
     // one conv1 tile).  Operands swapped as in conv1: a lane owns one output pixel and the channels 8g + 4*lh + e, adds
     // the residual from the pixel's staged input row and stores four 8-byte pieces of the pixel's 64-byte row.
     {
-      float4 pb[4], ps[4], ph[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        pb[g] = *reinterpret_cast<const float4*>(a.bias2 + 8 * g + 4 * lh);
-        ps[g] = *reinterpret_cast<const float4*>(a.scale2 + 8 * g + 4 * lh);
-        ph[g] = *reinterpret_cast<const float4*>(a.shift2 + 8 * g + 4 * lh);
-      }
+      const float* kc = sK + 96 + 4 * lh;
       const int kt[2] = {(wave + 1) & 7, ((wave + 1) & 7) + 8};
       const bool two = kt[1] < FB_OPIX / 32;
       int arow[2][9];
@@ -1000,21 +1039,12 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
       auto taps2 = [&](auto twoc) {
         constexpr bool TWO = decltype(twoc)::value;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const uint4 bw = *reinterpret_cast<const uint4*>(sW2 + boff + (tap * 2 + c) * 1024);
-            const uint4 r0 = *reinterpret_cast<const uint4*>(sT + arow[0][tap] + c * 32);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r0), acc[0], 0, 0, 0);
-            if (TWO) {
-              const uint4 r1 = *reinterpret_cast<const uint4*>(sT + arow[1][tap] + c * 32);
-              acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bw), __builtin_bit_cast(bf16x8, r1), acc[1], 0, 0, 0);
-            }
-          }
+        fb_taps<TWO>(sW2 + boff, sT, arow, acc);
       };
+      FBSTAMP(5);
       if (two) taps2(std::true_type{});
       else taps2(std::false_type{});
+      FBSTAMP(6);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         if (i == 1 && !two) break;
@@ -1023,10 +1053,8 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const uint2 rr = *reinterpret_cast<const uint2*>(sX + ((ff + 2 * FB_W) * T_LDH + 8 * g + 4 * lh) * 2);   // the block input
-          float v0 = (acc[i][4 * g + 0] + pb[g].x) * ps[g].x + ph[g].x;
-          float v1 = (acc[i][4 * g + 1] + pb[g].y) * ps[g].y + ph[g].y;
-          float v2 = (acc[i][4 * g + 2] + pb[g].z) * ps[g].z + ph[g].z;
-          float v3 = (acc[i][4 * g + 3] + pb[g].w) * ps[g].w + ph[g].w;
+          float v0, v1, v2, v3;
+          fb_bn4(kc + 8 * g, acc[i][4 * g + 0], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3], v0, v1, v2, v3);
           v0 += __builtin_bit_cast(float, rr.x << 16); v1 += __builtin_bit_cast(float, rr.x & 0xffff0000u);
           v2 += __builtin_bit_cast(float, rr.y << 16); v3 += __builtin_bit_cast(float, rr.y & 0xffff0000u);
           v0 = thin_relu(v0); v1 = thin_relu(v1); v2 = thin_relu(v2); v3 = thin_relu(v3);
@@ -1034,12 +1062,22 @@ __global__ __launch_bounds__(512, 1) void block32_fused_bf16(FusedBlockArgs a) {
         }
       }
     }
+    FBSTAMP(7);
     __syncthreads();          // every wave is done with sX and sT
+    FBSTAMP(8);
     if (has_next) write_x();
     __syncthreads();
+    FBSTAMP(9);
   }
 }
 
+#ifdef UMT_FB_STAMP
+}  // namespace umt
+extern "C" int umt_fb_stamps(unsigned long long* host16) {
+  return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(umt::g_fbstamp), 16 * sizeof(unsigned long long));
+}
+namespace umt {
+#endif
 // ---------------------------------------------------------------------------------------- launch
 // gfx950 only (umt_model_finalize checks the architecture): an MI355X has 256 CUs; a partition mode with fewer
 // only means some persistent workgroups queue behind others.
