@@ -45,9 +45,11 @@ constexpr int LDA = KC + 4;   // padded A row (floats): 16 consecutive pixels hi
 // PRE (kernel instances launched for layers WITH a residual): the residual rows of all the wave's
 // tiles are requested before the first transpose, so a workgroup exposes one memory latency, not one
 // per tile (the residual is the block input, long evicted from L2 when conv2 ends).
-template <bool PRE>
+// KPRE: the tile's bias / scale / shift quads were read at kernel start (kc[0..2]) instead of here, where their global-memory
+// latency would sit between the last MFMA and the first store of a one-tile workgroup.
+template <bool PRE, bool KPRE = false>
 __device__ __forceinline__ void store_tile(const f32x16& acc, const float4 (&res)[4], float* patch, int lane, int mbase,
-                                           int cobase, const ConvArgs& a) {
+                                           int cobase, const ConvArgs& a, const float4* kc = nullptr) {
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDA + li] = acc[r];
@@ -55,9 +57,9 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float4 (&res
   const int q = lane & 7, rsub = lane >> 3;
   const int co = cobase + 4 * q;
   if (co < a.cout_s) {
-    const float4 cb = *reinterpret_cast<const float4*>(a.bias + co);
-    const float4 cs = *reinterpret_cast<const float4*>(a.scale + co);
-    const float4 ch = *reinterpret_cast<const float4*>(a.shift + co);
+    const float4 cb = KPRE ? kc[0] : *reinterpret_cast<const float4*>(a.bias + co);
+    const float4 cs = KPRE ? kc[1] : *reinterpret_cast<const float4*>(a.scale + co);
+    const float4 ch = KPRE ? kc[2] : *reinterpret_cast<const float4*>(a.shift + co);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int row = 8 * k + rsub;
@@ -86,9 +88,21 @@ __device__ __forceinline__ void store_tile(const f32x16& acc, const float4 (&res
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int TM, int TN, bool PRE>
+// constants of the wave's TN cout tiles for store_tile<., true>: lane (q = lane & 7) owns channels cowave + 32 j + 4 q
+template <int TN>
+__device__ __forceinline__ void load_epilogue_constants(float4 (&kc)[TN][3], int lane, int cowave, const ConvArgs& a) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = min(cowave + j * 32 + 4 * (lane & 7), a.cout_w - 4);     // in range; unused where co >= cout_s
+    kc[j][0] = *reinterpret_cast<const float4*>(a.bias + co);
+    kc[j][1] = *reinterpret_cast<const float4*>(a.scale + co);
+    kc[j][2] = *reinterpret_cast<const float4*>(a.shift + co);
+  }
+}
+
+template <int TM, int TN, bool PRE, bool KPRE = false>
 __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], float* patch, int lane, int mwave, int cowave,
-                                         const ConvArgs& a) {
+                                         const ConvArgs& a, const float4 (*kc)[3] = nullptr) {
   float4 res[TN][TM][4];
   if (PRE) {
     const int q = lane & 7, rsub = lane >> 3;
@@ -108,7 +122,7 @@ __device__ __forceinline__ void epilogue(const f32x16 (&acc)[TM][TN], float* pat
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      store_tile<PRE>(acc[i][j], res[j][i], patch, lane, mwave + i * 32, cowave + j * 32, a);
+      store_tile<PRE, KPRE>(acc[i][j], res[j][i], patch, lane, mwave + i * 32, cowave + j * 32, a, KPRE ? kc[j] : nullptr);
 }
 
 }  // namespace umt

@@ -245,6 +245,11 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? UMT_F32_MINB_1TILE : 2)) void 
     }
   };
   load_b(bcur, 0, 0);
+  // epilogue constants requested now: a one-tile workgroup has nowhere else to hide their latency.  Only the 64 x 64 wave
+  // tiles take it (+0.6-1.1 % on the 128/256-channel layers; the 64-channel configuration lost 1.4 % to the registers)
+  constexpr bool KPRE = TM * TN == 4;
+  float4 kconst[TN][3];
+  if (KPRE) load_epilogue_constants<TN>(kconst, lane, n0 + wn * TN * 32, a);
 
   // A staging: thread t owns LDS slots idx = t + 256*k (row idx>>3, channel quad idx&7).  Loads are
   // unconditional at clamped addresses and zeroed afterwards, so they issue back to back; the range
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? UMT_F32_MINB_1TILE : 2)) void 
 
   // ---- epilogue ----
   float* patch = sA + wave * 32 * LDA;
-  epilogue<TM, TN, RES>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a);
+  epilogue<TM, TN, RES, KPRE>(acc, patch, lane, m0 + wm * TM * 32, n0 + wn * TN * 32, a, kconst);
 }
 
 // ---------------------------------------------------------------------------------------------
