@@ -242,10 +242,12 @@ int main(int argc, char** argv) {
       {
         unsigned long long h[2][64][4];
         hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamp), sizeof(h));
-        for (int ph = 0; ph < 22; ++ph)
+        for (int ph = 0; ph < 22; ++ph) {
+          printf("  ph %2d  pre-mfma g0 %6lld g1 %6lld", ph, (long long)(h[0][ph][3] - h[0][ph][0]), (long long)(h[1][ph][3] - h[1][ph][0]));
           printf("  ph %2d  g0: start %8llu work %7llu (epi %7llu)   g1: start %8llu work %7llu (epi %7llu)\n", ph,
                  h[0][ph][0] - h[0][0][0], h[0][ph][1] - h[0][ph][0], h[0][ph][2] > h[0][ph][0] ? h[0][ph][2] - h[0][ph][0] : 0,
                  h[1][ph][0] - h[0][0][0], h[1][ph][1] - h[1][ph][0], h[1][ph][2] > h[1][ph][0] ? h[1][ph][2] - h[1][ph][0] : 0);
+        }
       }
 #endif
       hipFree(in); hipFree(out); hipFree(res); hipFree(w); hipFree(vec);

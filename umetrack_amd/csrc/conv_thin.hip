@@ -109,6 +109,38 @@ __device__ __forceinline__ unsigned thin_pack_bf16x2(float x, float y) {
   return (unsigned)__builtin_bit_cast(unsigned short, p) | ((unsigned)__builtin_bit_cast(unsigned short, r) << 16);
 }
 
+// Batch norm, residual add, ReLU and the bf16 rounding of eight consecutive channels of one pixel, written on register
+// PAIRS: 4 packed adds + 4 packed fused multiply-adds (+ 4 packed adds for the residual), 8 integer max and 4 packed
+// conversions.  Each component rounds exactly as the scalar (x + bias) * scale + shift, += residual, max(x, 0), (bf16)
+// sequence does.  The same arithmetic on float4 fields compiled to pairs of the wrong components with ~40 register moves
+// per call around them -- and vector instructions are what an epilogue wave is short of while the other group's MFMAs
+// run on its SIMD (tools/mfma_peak.hip, mix: a saturated matrix pipe leaves a second wave 2.5 vector instructions per
+// 32-cycle MFMA, a third of the rate it has alone).
+typedef float thin_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 thin_bf16x2 __attribute__((ext_vector_type(2)));
+typedef int thin_i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int thin_u32x4 __attribute__((ext_vector_type(4)));
+template <bool RES>
+__device__ __forceinline__ uint4 thin_bn_res_relu_pack8(float4 v, float4 u, const float4& cb0, const float4& cb1, const float4& cs0,
+                                                        const float4& cs1, const float4& ch0, const float4& ch1, thin_u32x4 rr,
+                                                        int relu_floor) {
+  thin_f32x2 p[4] = {{v.x, v.y}, {v.z, v.w}, {u.x, u.y}, {u.z, u.w}};
+  const thin_f32x2 b[4] = {{cb0.x, cb0.y}, {cb0.z, cb0.w}, {cb1.x, cb1.y}, {cb1.z, cb1.w}};
+  const thin_f32x2 sc[4] = {{cs0.x, cs0.y}, {cs0.z, cs0.w}, {cs1.x, cs1.y}, {cs1.z, cs1.w}};
+  const thin_f32x2 sh[4] = {{ch0.x, ch0.y}, {ch0.z, ch0.w}, {ch1.x, ch1.y}, {ch1.z, ch1.w}};
+  unsigned o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    p[i] = __builtin_elementwise_fma(p[i] + b[i], sc[i], sh[i]);
+    if (RES) p[i] += (thin_f32x2){__builtin_bit_cast(float, rr[i] << 16), __builtin_bit_cast(float, rr[i] & 0xffff0000u)};
+    // ReLU as an integer max on the bit patterns (relu_floor = 0, or INT_MIN for none), on the PAIR: written per component
+    // (p.x = max(..), p.y = max(..)) this compiler converts component x twice and drops y
+    const thin_i32x2 pi = __builtin_elementwise_max(__builtin_bit_cast(thin_i32x2, p[i]), (thin_i32x2){relu_floor, relu_floor});
+    o[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(thin_f32x2, pi), thin_bf16x2));
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 template <int TM, bool RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_thin32_bf16(ThinArgs a) {
   constexpr int BM = 128 * TM;
@@ -274,6 +306,12 @@ constexpr int W64_BM = 128;
 constexpr int W64_WMAX = 24;
 constexpr int W64_WBYTES = 9 * 64 * 64 * 2;    // packed weights [9][4][2][64][8] bf16
 constexpr int W64_CBYTES = 3 * 64 * 4;         // bias, scale, shift
+#ifndef W64_AHEAD
+#define W64_AHEAD 2
+#endif
+#ifndef W64_EPI_PRIO
+#define W64_EPI_PRIO 3
+#endif
 
 template <bool RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
@@ -310,29 +348,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
   const GroupWalk g0 = group_walk(a.ntiles, 0);
   const int nphase = 2 * g0.count + 1;
 
+  // One halo range = rows [tile * BM - W - 1, + rows) of the activation tensor, clipped to [0, M): a contiguous run, read
+  // through a buffer descriptor that covers exactly that run, so the rows outside it come back as zeros from the
+  // hardware range check (offsets below the run wrap to > 2^31).  No validity mask is carried from the loads to the LDS
+  // stores: with one, the register allocator parked the mask in a register of the load destinations and made every
+  // MFMA phase wait for the HBM round trip of the loads it had just issued (2700 of its 5300 cycles).
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   uint4 areg[NLD];
-  unsigned aok = 0;
-  auto load_a = [&](int tile) {
+  auto load_a = [&](int tile_v) {
+    const int tile = __builtin_amdgcn_readfirstlane(tile_v);
     const int gbase = tile * BM - W - 1;
-    aok = 0;
+    const int g_lo = gbase > 0 ? gbase : 0, g_hi = gbase + rows < a.M ? gbase + rows : a.M;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(in) + (size_t)g_lo * 64, 0, g_hi > g_lo ? (g_hi - g_lo) * 128 : 0, 0x00020000);
+    const int shift = (g_lo - gbase) * 128;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int idx = tid + 256 * k;
-      const int r = idx >> 3, qq = idx & 7;
-      const int g = gbase + r;
-      const bool ok = r < rows && g >= 0 && g < a.M;
-      const size_t off = ok ? (size_t)g * 64 + 8 * qq : 0;
-      areg[k] = *reinterpret_cast<const uint4*>(in + off);
-      aok |= (ok ? 1u : 0u) << k;
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16 - shift, 0, 0);
+      areg[k] = make_uint4(v.x, v.y, v.z, v.w);
     }
   };
   auto write_a = [&]() {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int idx = tid + 256 * k;
-      uint4 v = areg[k];
-      if (!((aok >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
-      if ((idx >> 3) < rows) *reinterpret_cast<uint4*>(sA + ((idx >> 3) * W64_LDA + 8 * (idx & 7)) * 2) = v;
+      if ((idx >> 3) < rows) *reinterpret_cast<uint4*>(sA + ((idx >> 3) * W64_LDA + 8 * (idx & 7)) * 2) = areg[k];
     }
   };
 
@@ -343,27 +384,22 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
   }
   __syncthreads();
 
+  const int relu_floor = a.relu ? 0 : (int)0x80000000;
   f32x16 acc[2];
-  uint4 res[2][2];
+  // The residual rows of a tile are requested in its MFMA phase and used in its epilogue phase.  They are loaded into
+  // accumulation registers by hand: as an ordinary load into vector registers the allocator moved half of one destination
+  // quad out of the way of an address temporary right after the request, which cost every MFMA phase an HBM round trip.
+  // The compiler does not count these loads, so the epilogue waits for them itself (its own counted waits stay safe: the
+  // load counter retires in order, and extra loads in it only make a counted wait stricter).
+  u32x4 res[2][2];
   for (int ph = 0; ph < nphase; ++ph) {
+    STAMP(ph, 0);
     const int j = (ph - group) >> 1;
     const bool mfma_phase = ((ph - group) & 1) == 0;
     if (ph >= group && j < gw.count) {
       const int t = gw.first + j * gw.step;
       const int mw = t * BM + wave * 32;
       if (mfma_phase) {
-        if (j + 1 < gw.count) load_a(t + gw.step);
-        if (RES) {
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const int m = mw + 16 * k + rsub;
-              const size_t off = m < a.M ? (size_t)m * 64 + n * 32 + 8 * q : 0;
-              res[n][k] = *reinterpret_cast<const uint4*>(resid + off);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
         int arow[9];      // byte offset of the lane's operand row per tap; the zero row where padded
         {
           const unsigned mk = border_mask(mw + li, a.M, H, W, a.mg_hw, a.mg_w);
@@ -376,22 +412,49 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
         for (int n = 0; n < 2; ++n)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < gw.count) load_a(t + gw.step);
+        if (RES) {
 #pragma unroll
-        for (int chunk = 0; chunk < 2; ++chunk)
+          for (int n = 0; n < 2; ++n)
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-              const int c16 = chunk * 2 + c;
-              const uint4 av = *reinterpret_cast<const uint4*>(sA + arow[tap] + c16 * 32);
-#pragma unroll
-              for (int n = 0; n < 2; ++n) {
-                const uint4 bv = *reinterpret_cast<const uint4*>(bl + (tap * 4 + c16) * 2048 + n * 512);
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
-                                                                 acc[n], 0, 0, 0);
-              }
+            for (int k = 0; k < 2; ++k) {
+              const int m = mw + 16 * k + rsub;
+              const size_t off = m < a.M ? (size_t)m * 64 + n * 32 + 8 * q : 0;
+              const uint16_t* rp = resid + off;
+              asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(res[n][k]) : "v"(rp) : "memory");
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          // k-step st = (chunk, tap, c); its three fragments are read from LDS W64_AHEAD steps before its MFMAs and
+          // pinned there (read in the step that uses them, every MFMA pair waited a full LDS round trip)
+          STAMP(ph, 3);
+          constexpr int NS = 36, D = W64_AHEAD;
+          uint4 av[D + 1], bv0[D + 1], bv1[D + 1];
+          auto rd = [&](int slot, int st) {
+            const int chunk = st / 18, tap = (st % 18) >> 1, c16 = chunk * 2 + (st & 1);
+            av[slot] = *reinterpret_cast<const uint4*>(sA + arow[tap] + c16 * 32);
+            bv0[slot] = *reinterpret_cast<const uint4*>(bl + (tap * 4 + c16) * 2048);
+            bv1[slot] = *reinterpret_cast<const uint4*>(bl + (tap * 4 + c16) * 2048 + 512);
+          };
+#pragma unroll
+          for (int st = 0; st < D; ++st) rd(st, st);
+#pragma unroll
+          for (int st = 0; st < NS; ++st) {
+            if (st + D < NS) rd((st + D) % (D + 1), st + D);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[st % (D + 1)]),
+                                                             __builtin_bit_cast(bf16x8, bv0[st % (D + 1)]), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[st % (D + 1)]),
+                                                             __builtin_bit_cast(bf16x8, bv1[st % (D + 1)]), acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       } else {
+        __builtin_amdgcn_s_setprio(W64_EPI_PRIO);      // as in conv3x3_stream128_bf16: the epilogue phase issues first
+        if (RES)
+          asm volatile("s_waitcnt vmcnt(0)" : "+a"(res[0][0]), "+a"(res[0][1]), "+a"(res[1][0]), "+a"(res[1][1])::"memory");
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const int co = n * 32 + 8 * q;
@@ -405,33 +468,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
           for (int k = 0; k < 2; ++k) {
             const int row = 16 * k + rsub;
             const int m = mw + row;
-            float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
-            float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
-            v.x = (v.x + cb0.x) * cs0.x + ch0.x; v.y = (v.y + cb0.y) * cs0.y + ch0.y;
-            v.z = (v.z + cb0.z) * cs0.z + ch0.z; v.w = (v.w + cb0.w) * cs0.w + ch0.w;
-            u.x = (u.x + cb1.x) * cs1.x + ch1.x; u.y = (u.y + cb1.y) * cs1.y + ch1.y;
-            u.z = (u.z + cb1.z) * cs1.z + ch1.z; u.w = (u.w + cb1.w) * cs1.w + ch1.w;
-            if (RES) {
-              const uint4 rr = res[n][k];
-              v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
-              v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
-              u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
-              u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
-            }
-            if (a.relu) {
-              v.x = thin_relu(v.x); v.y = thin_relu(v.y); v.z = thin_relu(v.z); v.w = thin_relu(v.w);
-              u.x = thin_relu(u.x); u.y = thin_relu(u.y); u.z = thin_relu(u.z); u.w = thin_relu(u.w);
-            }
-            if (m < a.M)
-              *reinterpret_cast<uint4*>(out + (size_t)m * 64 + co) =
-                  make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y),
-                             thin_pack_bf16x2(u.z, u.w));
+            const float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+            const float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+            const uint4 o = thin_bn_res_relu_pack8<RES>(v, u, cb0, cb1, cs0, cs1, ch0, ch1, RES ? res[n][k] : u32x4{0, 0, 0, 0}, relu_floor);
+            if (m < a.M) *reinterpret_cast<uint4*>(out + (size_t)m * 64 + co) = o;
           }
           __builtin_amdgcn_wave_barrier();
+          if (n == 0) STAMP(ph, 3);
         }
+        STAMP(ph, 2);
         if (j + 1 < gw.count) write_a();
+        __builtin_amdgcn_s_setprio(0);
       }
     }
+    STAMP(ph, 1);
     __syncthreads();
   }
 }
