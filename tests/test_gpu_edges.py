@@ -140,8 +140,8 @@ def test_layer_timing_covers_every_backbone_launch():
 
 @pytest.mark.gpu
 def test_fp32_persistent_stage1_kernel_bit_identical_to_halo_kernel(tmp_path):
-    """fp32 mode, 32 -> 32 layers of stage 1: from 57 crops up they run on the persistent LDS-weights kernel of
-    conv_thin.hip (conv3x3_wlds32_f32); with UMT_CONV_NOTHIN_F32=1 (read once per process, hence the child process) on
+    """fp32 mode, 32 -> 32 layers of stage 1: from 57 crops up they run on a persistent LDS-weights kernel of
+    conv_thin.hip (conv3x3_pipe32_f32; conv3x3_wlds32_f32 with UMT_CONV_NOPIPE32=1); with UMT_CONV_NOTHIN_F32=1 (read once per process, hence the child process) on
     conv3x3s1_halo_f32.  Same k order and epilogue arithmetic, so the backbone features must agree bit for bit; 131
     crops leave the last 128-pixel tiles of the walk ragged, 57 is the switch-over size."""
     import os
@@ -218,5 +218,26 @@ def test_persistent_stride2_kernel_bit_identical_to_one_tile_kernel(monkeypatch)
 
     got = run()
     monkeypatch.setenv("UMT_CONV_NOS2P", "1")
+    ref = run()
+    assert torch.isfinite(got).all() and torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_fp32_single_role_stage1_kernel_bit_identical_to_two_group_kernel(monkeypatch):
+    """fp32 mode, 32 -> 32 layers of stage 1: conv3x3_pipe32_f32 (every wave carries its own epilogue, halo stores and loads
+    between its MFMAs; operands swapped, 256-pixel tiles) against conv3x3_wlds32_f32 (UMT_CONV_NOPIPE32=1, read per model
+    handle; two groups of waves alternating MFMA and epilogue phases, 128-pixel tiles).  Same k order and epilogue
+    arithmetic: bit-identical features.  57 crops is the switch-over size, 131 leave the last tiles of the walk ragged,
+    900 give every workgroup several tiles (the steady state of the pipeline, both LDS buffers in use)."""
+    import torch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    img = torch.rand(900, 96, 96, generator=torch.Generator().manual_seed(79)).cuda()
+
+    def run():
+        gm = model_from_state_dict(arch.make_synthetic_state(7)).to("cuda")
+        return torch.cat([gm.backbone(img[:57]), gm.backbone(img[:131]), gm.backbone(img)]).cpu()
+
+    got = run()
+    monkeypatch.setenv("UMT_CONV_NOPIPE32", "1")
     ref = run()
     assert torch.isfinite(got).all() and torch.equal(got, ref)

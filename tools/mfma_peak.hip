@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void k_mix(float* out, int) {
   const int wave = threadIdx.x >> 6;
   constexpr int mfma_first = !(mode & 4);          // mode & 4: the FMA waves are the older ones (0-3); mode & 8: they raise their priority
   const int t0 = mfma_first ? 0 : 256, t1 = 256 - t0;
-  if ((wave < 4) == (mfma_first != 0)) {
+  if ((mode & 512) || (wave < 4) == (mfma_first != 0)) {      // mode & 512: all eight waves take the MFMA role
     if (!(mode & 1)) return;
     bf16x8 a, b;
     for (int i = 0; i < 8; ++i) { a[i] = (__bf16)rnd(threadIdx.x * 16 + i); b[i] = (__bf16)rnd(threadIdx.x * 16 + 8 + i + blockIdx.x * 4096); }
@@ -195,14 +195,15 @@ __global__ __launch_bounds__(512) void k_mix(float* out, int) {
 }
 
 static void run_mix(float* out) {
-  const int modes[] = {1, 2, 3, 3 | 8, 3 | 4, 3 | 4 | 8, 3 | 16, 3 | 32, 3 | 48, 1 | (2 << 6), 1 | (4 << 6), 1 | (6 << 6)};
+  const int modes[] = {1, 2, 3, 3 | 8, 3 | 4, 3 | 4 | 8, 3 | 16, 3 | 32, 3 | 48, 1 | (2 << 6), 1 | (4 << 6), 1 | (6 << 6), 1 | 512, 1 | 512 | (4 << 6), 1 | 512 | (6 << 6)};
   const char* names[] = {"MFMA waves only", "FMA waves only", "both, MFMA waves older", "both, MFMA older, FMA prio 3", "both, FMA waves older",
                          "both, FMA older, FMA prio 3", "both, s_nop 7 after each MFMA", "both, 2 x s_nop 7", "both, 3 x s_nop 7",
-                         "MFMA waves only, +2 own FMAs", "MFMA waves only, +4 own FMAs", "MFMA waves only, +6 own FMAs"};
+                         "MFMA waves only, +2 own FMAs", "MFMA waves only, +4 own FMAs", "MFMA waves only, +6 own FMAs",
+                         "8 MFMA waves", "8 MFMA waves, +4 own FMAs", "8 MFMA waves, +6 own FMAs"};
   typedef void (*kfn)(float*, int);
   const kfn fns[] = {k_mix<1>, k_mix<2>, k_mix<3>, k_mix<3 | 8>, k_mix<3 | 4>, k_mix<3 | 4 | 8>, k_mix<3 | 16>, k_mix<3 | 32>, k_mix<3 | 48>,
-                     k_mix<1 | (2 << 6)>, k_mix<1 | (4 << 6)>, k_mix<1 | (6 << 6)>};
-  for (int k = 0; k < 12; ++k) {
+                     k_mix<1 | (2 << 6)>, k_mix<1 | (4 << 6)>, k_mix<1 | (6 << 6)>, k_mix<1 | 512>, k_mix<1 | 512 | (4 << 6)>, k_mix<1 | 512 | (6 << 6)>};
+  for (int k = 0; k < 15; ++k) {
     const int mode = modes[k];
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(fns[k], dim3(256), dim3(512), 0, 0, out, mode);
     (void)hipDeviceSynchronize();

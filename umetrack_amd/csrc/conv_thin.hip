@@ -848,6 +848,188 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds32_f32(ThinArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ fp32, 32 -> 32, one role per wave
+// conv3x3_wlds32_f32 with the two-group scheme taken out.  What tools/mfma_peak.hip (mix) showed about this chip: a wave
+// that issues MFMAs back to back leaves the OTHER waves of its SIMD no vector-instruction slot at all (wave priority and
+// age change nothing), while up to six vector instructions of the SAME wave per MFMA cost nothing.  So in the two-group
+// kernel the epilogue group only ran while the MFMA group stalled, and a phase lasted the MFMA loop PLUS the other
+// group's vector work (11.5 k cycles for 9.2 k of MFMAs).  Here every wave does everything for its own 32 pixels, in
+// the shadow of its own MFMAs: the 36 k-steps (4 MFMAs = 256 matrix-pipe cycles each) of tile j carry, one piece per
+// step, the LDS stores of the next tile's halo range, the epilogue of tile j-1 (accumulators kept in registers), the
+// loads of the halo range after next and of tile j's residual rows, and the next tile's border arithmetic.  Eight
+// waves = a 256-pixel tile, halo ranges double-buffered in LDS, one barrier per tile.  The MFMA operands are swapped
+// (weights as the row operand): a lane owns 16 channels of ONE pixel, so the epilogue needs no transposing patch and
+// stores four float4 per lane.  k order (tap, 8-channel group, element) and the epilogue arithmetic are
+// conv3x3s1_halo_f32's; swapping the operands transposes the result tile and nothing else: bit-identical results.
+constexpr int P32_BM = 256;
+constexpr int P32_CBYTES = 3 * 32 * 4;
+
+#ifdef UMT_STAMP
+#define PSTAMP(j, k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (j) < 64) g_stamp[threadIdx.x >> 8][j][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(j, k) do {} while (0)
+#endif
+template <bool RES>
+__global__ __launch_bounds__(512, 1) void conv3x3_pipe32_f32(ThinArgs a) {
+  constexpr int BM = P32_BM;
+  constexpr int NLD = ((BM + 2 * 48 + 2) * 8 + 511) / 512;   // float4 slots per thread for one halo range (6)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a_bytes = (rows + 1) * F32_LDA * 4;                  // halo range + the all-zero row (multiple of 16)
+  unsigned char* sW = smem_p;
+  const float* sC = reinterpret_cast<const float*>(smem_p + F32_WBYTES);
+  unsigned char* sA0 = smem_p + F32_WBYTES + P32_CBYTES;
+  const int li = lane & 31, lh = lane >> 5;
+  const float* in = reinterpret_cast<const float*>(a.in);
+  const float* resid = reinterpret_cast<const float*>(a.residual);
+  float* out = reinterpret_cast<float*>(a.out);
+  const int relu_floor = a.relu ? 0 : (int)0x80000000;
+
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+    for (int i = tid; i < F32_WBYTES / 16; i += 512) *reinterpret_cast<uint4*>(sW + 16 * i) = wp[i];
+    float* c = reinterpret_cast<float*>(smem_p + F32_WBYTES);
+    if (tid < 32) {
+      c[tid] = a.bias[tid];
+      c[32 + tid] = a.scale[tid];
+      c[64 + tid] = a.shift[tid];
+    }
+    if (tid < 2 * (F32_LDA / 4))       // the all-zero row of both buffers
+      *reinterpret_cast<float4*>(sA0 + (tid / (F32_LDA / 4)) * a_bytes + (rows * F32_LDA + 4 * (tid % (F32_LDA / 4))) * 4) =
+          make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  int t0, tstep, tend;
+  tile_walk(a.ntiles, t0, tstep, tend);
+  const int count = t0 < tend ? (tend - t0 + tstep - 1) / tstep : 0;
+
+  // One halo range = rows [tile * BM - W - 1, + rows) clipped to [0, M), read through a buffer descriptor that covers
+  // exactly that run: rows outside it (and everything, when there is no such tile) come back as zeros
+  float4 areg[NLD];
+  __amdgpu_buffer_rsrc_t a_rs;
+  int a_shift = 0;
+  auto load_a_begin = [&](int tile, bool have) {      // both workgroup-uniform
+    const int gbase = tile * BM - W - 1;
+    const int g_lo = gbase > 0 ? gbase : 0, g_hi = gbase + rows < a.M ? gbase + rows : a.M;
+    a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in) + (size_t)g_lo * 32, 0,
+                                             have && g_hi > g_lo ? (g_hi - g_lo) * 128 : 0, 0x00020000);
+    a_shift = (g_lo - gbase) * 128;
+  };
+  auto load_a_one = [&](int k) {
+    areg[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (tid + 512 * k) * 16 - a_shift, 0, 0));
+  };
+  auto write_a_one = [&](unsigned char* sA, int k) {
+    const int idx = tid + 512 * k;
+    if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + ((idx >> 3) * F32_LDA + 4 * (idx & 7)) * 4) = areg[k];
+  };
+  // byte offset of the lane's operand row per tap (the zero row where padded) for the wave tile that starts at pixel row mw
+  auto set_arow = [&](int (&ar)[9], int mw) {
+    const unsigned mk = border_mask(mw + li, a.M, H, W, a.mg_hw, a.mg_w);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+      ar[tap] = ((((mk >> tap) & 1u) ? wave * 32 + li + (tap / 3) * W + (tap % 3) : rows) * F32_LDA + 4 * lh) * 4;
+  };
+  auto relu1 = [&](float v) { return __builtin_bit_cast(float, max(__builtin_bit_cast(int, v), relu_floor)); };
+
+  f32x16 acc, accp;
+  float4 res[4];
+  int arow[9], arow_n[9];
+  int mw_p = 0;
+  // channels 8g + 4lh .. + 3 of pixel row m: (acc + bias) * scale + shift (+ residual), ReLU, one float4 store
+  auto epilogue_piece = [&](int g, int m) {
+    const float* kc = sC + 8 * g + 4 * lh;
+    const float4 cb = *reinterpret_cast<const float4*>(kc), cs = *reinterpret_cast<const float4*>(kc + 32),
+                 ch = *reinterpret_cast<const float4*>(kc + 64);
+    f32x2 lo = __builtin_elementwise_fma((f32x2){accp[4 * g], accp[4 * g + 1]} + (f32x2){cb.x, cb.y}, (f32x2){cs.x, cs.y},
+                                         (f32x2){ch.x, ch.y});
+    f32x2 hi = __builtin_elementwise_fma((f32x2){accp[4 * g + 2], accp[4 * g + 3]} + (f32x2){cb.z, cb.w}, (f32x2){cs.z, cs.w},
+                                         (f32x2){ch.z, ch.w});
+    if (RES) {
+      lo += (f32x2){res[g].x, res[g].y};
+      hi += (f32x2){res[g].z, res[g].w};
+    }
+    const float o0 = lo.x, o1 = lo.y, o2 = hi.x, o3 = hi.y;
+    if (m < a.M) *reinterpret_cast<float4*>(out + (size_t)m * 32 + 8 * g + 4 * lh) = make_float4(relu1(o0), relu1(o1), relu1(o2), relu1(o3));
+  };
+  auto load_res_one = [&](int g, int m) {
+    const size_t off = m < a.M ? (size_t)m * 32 + 8 * g + 4 * lh : 0;
+    res[g] = *reinterpret_cast<const float4*>(resid + off);
+  };
+
+  if (count > 0) {
+    load_a_begin(t0, true);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) load_a_one(k);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) write_a_one(sA0, k);
+    load_a_begin(t0 + tstep, count > 1);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) load_a_one(k);
+    set_arow(arow, t0 * BM + wave * 32);
+  }
+  __syncthreads();
+
+  for (int j = 0; j < count; ++j) {
+    const int t = t0 + j * tstep;
+    const int mw = t * BM + wave * 32;
+    const unsigned char* sA = sA0 + (j & 1) * a_bytes;
+    unsigned char* sAn = sA0 + ((j + 1) & 1) * a_bytes;
+    PSTAMP(j, 0);
+    const bool have_next = j + 1 < count, have_prev = j > 0;
+    const unsigned char* bl = sW + (lh * 32 + li) * 16;      // + (tap * 4 + c8) * 1024
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 av[2], bv[2];
+    av[0] = *reinterpret_cast<const float4*>(sA + arow[0]);
+    bv[0] = *reinterpret_cast<const float4*>(bl);
+#pragma unroll
+    for (int st = 0; st < 36; ++st) {
+      if (st + 1 < 36) {
+        av[(st + 1) & 1] = *reinterpret_cast<const float4*>(sA + arow[(st + 1) >> 2] + ((st + 1) & 3) * 32);
+        bv[(st + 1) & 1] = *reinterpret_cast<const float4*>(bl + (st + 1) * 1024);
+      }
+      // the piece of side work this step carries
+      if (st < NLD) {
+        if (have_next) write_a_one(sAn, st);                                   // halo range of tile j+1 -> the other buffer
+      } else if (st < 6 + 16) {
+        if (have_prev && ((st - 6) & 3) == 0) epilogue_piece((st - 6) >> 2, mw_p + li);   // tile j-1, one channel quad per 4 steps
+      } else if (st == 22) {
+        load_a_begin(t + 2 * tstep, j + 2 < count);
+        load_a_one(0);
+      } else if (st < 22 + NLD) {
+        load_a_one(st - 22);
+      } else if (st < 28 + 4) {
+        if (RES) load_res_one(st - 28, mw + li);
+      } else if (st == 32) {
+        if (have_next) set_arow(arow_n, mw + tstep * BM);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 x = av[st & 1], y = bv[st & 1];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, x.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, x.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, x.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, x.w, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PSTAMP(j, 2);
+    accp = acc;
+    mw_p = mw;
+    if (have_next) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) arow[tap] = arow_n[tap];
+    }
+    PSTAMP(j, 1);
+    __syncthreads();
+  }
+  if (count > 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) epilogue_piece(g, mw_p + li);
+  }
+}
+
 // ------------------------------------------------------------------------------ bf16, fused BasicBlock 32 -> 32 -> 32
 // A whole stage-1 BasicBlock (lib/models/backbone_resnet.py:56-72, planes = 32, stride 1: conv1 + BN + ReLU, conv2 + BN +
 // residual + ReLU) in one kernel, UMT_PREC_BF16.  Unfused, a block moves 735 KB per crop through HBM (conv1 reads x and
@@ -1199,6 +1381,9 @@ static size_t f32_lds_bytes(int w) {
 static_assert((size_t)F32_WBYTES + 2 * ((size_t)(F32_BM + 2 * 48 + 2 + 1) * F32_LDA * 4 + 4 * 32 * F32_LDA * sizeof(float)) <= 160 * 1024,
               "conv3x3_wlds32_f32: LDS budget");
 
+static size_t p32_lds_bytes(int w) { return (size_t)F32_WBYTES + P32_CBYTES + 2 * (size_t)(P32_BM + 2 * w + 2 + 1) * F32_LDA * 4; }
+static_assert((size_t)F32_WBYTES + P32_CBYTES + 2 * (size_t)(P32_BM + 2 * 48 + 2 + 1) * F32_LDA * 4 <= 160 * 1024, "conv3x3_pipe32_f32: LDS budget");
+
 bool conv_thin_f32_applicable(const ConvLayer& L, int w) {
   return !(L.flags & (CONV_NO_THIN_F32 | CONV_NO_THIN)) && L.taps == 9 && L.stride == 1 && L.cin_s == 32 && L.cout_s == 32 && L.cout_w == 32 && w <= 48;
 }
@@ -1214,6 +1399,13 @@ int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int 
   a.ntiles = (int)((M + F32_BM - 1) / F32_BM);
   a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
+  if (!(L.flags & CONV_NO_PIPE32)) {
+    a.ntiles = (int)((M + P32_BM - 1) / P32_BM);
+    auto kp = residual ? conv3x3_pipe32_f32<true> : conv3x3_pipe32_f32<false>;
+    hipLaunchKernelGGL(kp, dim3(grid_for(a.ntiles, 1)), dim3(512), p32_lds_bytes(w), stream, a);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   auto kern = residual ? conv3x3_wlds32_f32<true> : conv3x3_wlds32_f32<false>;
   hipLaunchKernelGGL(kern, dim3(grid_for(a.ntiles, 1)), dim3(512), f32_lds_bytes(w), stream, a);
   UMT_CHECK_HIP(hipGetLastError());
@@ -1224,6 +1416,8 @@ int conv_thin_prepare_device() {      // largest request: W = 48
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(block32_fused_bf16), FB_LDS));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<false>), f32_lds_bytes(48)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds32_f32<true>), f32_lds_bytes(48)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_pipe32_f32<false>), p32_lds_bytes(48)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_pipe32_f32<true>), p32_lds_bytes(48)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<false>), s128_lds_bytes(S128_WMAX)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<true>), s128_lds_bytes(S128_WMAX)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX)));
