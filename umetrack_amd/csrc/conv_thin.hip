@@ -532,6 +532,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
     c[256 + threadIdx.x] = a.shift[threadIdx.x];
   }
   const int q = lane & 3, rsub = lane >> 2;
+  const int relu_floor = a.relu ? 0 : (int)0x80000000;
 
   const GroupWalk gw = group_walk(a.ntiles, group);
   const GroupWalk g0 = group_walk(a.ntiles, 0);
@@ -667,27 +668,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_stream128_bf16(ThinArgs a) {
             for (int k = 0; k < 2; ++k) {
               const int row = 16 * k + rsub;
               const int m = mw + i * 32 + row;
-              float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
-              float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
-              v.x = (v.x + cb0.x) * cs0.x + ch0.x; v.y = (v.y + cb0.y) * cs0.y + ch0.y;
-              v.z = (v.z + cb0.z) * cs0.z + ch0.z; v.w = (v.w + cb0.w) * cs0.w + ch0.w;
-              u.x = (u.x + cb1.x) * cs1.x + ch1.x; u.y = (u.y + cb1.y) * cs1.y + ch1.y;
-              u.z = (u.z + cb1.z) * cs1.z + ch1.z; u.w = (u.w + cb1.w) * cs1.w + ch1.w;
-              if (RES) {
-                const uint4 rr = res[i][n][k];
-                v.x += __builtin_bit_cast(float, rr.x << 16); v.y += __builtin_bit_cast(float, rr.x & 0xffff0000u);
-                v.z += __builtin_bit_cast(float, rr.y << 16); v.w += __builtin_bit_cast(float, rr.y & 0xffff0000u);
-                u.x += __builtin_bit_cast(float, rr.z << 16); u.y += __builtin_bit_cast(float, rr.z & 0xffff0000u);
-                u.z += __builtin_bit_cast(float, rr.w << 16); u.w += __builtin_bit_cast(float, rr.w & 0xffff0000u);
-              }
-              if (a.relu) {
-                v.x = thin_relu(v.x); v.y = thin_relu(v.y); v.z = thin_relu(v.z); v.w = thin_relu(v.w);
-                u.x = thin_relu(u.x); u.y = thin_relu(u.y); u.z = thin_relu(u.z); u.w = thin_relu(u.w);
-              }
-              if (m < a.M)
-                *reinterpret_cast<uint4*>(out + (size_t)m * 128 + co) =
-                    make_uint4(thin_pack_bf16x2(v.x, v.y), thin_pack_bf16x2(v.z, v.w), thin_pack_bf16x2(u.x, u.y),
-                               thin_pack_bf16x2(u.z, u.w));
+              const float4 v = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q);
+              const float4 u = *reinterpret_cast<const float4*>(patch + row * T_LDP + 8 * q + 4);
+              thin_u32x4 rr = {0, 0, 0, 0};
+              if (RES) rr = thin_u32x4{res[i][n][k].x, res[i][n][k].y, res[i][n][k].z, res[i][n][k].w};
+              const uint4 o = thin_bn_res_relu_pack8<RES>(v, u, cb0, cb1, cs0, cs1, ch0, ch1, rr, relu_floor);
+              if (m < a.M) *reinterpret_cast<uint4*>(out + (size_t)m * 128 + co) = o;
             }
             __builtin_amdgcn_wave_barrier();
           }
