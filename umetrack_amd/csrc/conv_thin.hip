@@ -52,6 +52,11 @@ __device__ unsigned long long g_stamp[2][64][4];
 #else
 #define STAMP(ph, k) do {} while (0)
 #endif
+#ifdef UMT_STAMP
+#define PSTAMP(j, k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (j) < 64) g_stamp[threadIdx.x >> 8][j][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PSTAMP(j, k) do {} while (0)
+#endif
 
 __device__ __forceinline__ int thin_div(int m, int d, unsigned mg) {      // floor(m / d), 0 <= m < 2^31
   int q = (int)__umulhi((unsigned)m, mg);
@@ -486,6 +491,276 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ 64 -> 64, one role per wave
+// conv3x3_wlds64_bf16 restructured as conv3x3_pipe32_f32 is (see there for why): every wave carries the epilogue of its
+// previous tile, the LDS stores of the next halo range, the loads of the range after next and of its residual rows, and
+// the next tile's border arithmetic between its own MFMAs.  Four waves, one per SIMD, each 64 pixels x 64 channels (2 x 2
+// MFMA tiles: one ds_read_b128 per MFMA; with 32 x 64 per wave and eight waves the LDS array, at 1.5 reads per MFMA,
+// set the pace and the kernel was no faster than the two-group one), 256-pixel tiles, 36 k-steps of four MFMAs.  Halo
+// ranges double-buffered in LDS beside the packed weights (162.9 KB in all), one barrier per tile, the accumulators of
+// two consecutive tiles alternate between two register sets.  Operands swapped (weights as the row operand): a lane owns
+// 2 x 16 channels of two pixels and stores 8-byte quads, no transposing patch.  k order (32-channel chunk, tap,
+// 16-channel group) and the epilogue arithmetic are conv3x3s1_halo_bf16's: bit-identical.
+// STATUS: opt-in (UMT_CONV_PIPE64=1), not the default.  Its MFMA + LDS loop alone (-DP64_NOSIDE: no side work, wrong
+// results) runs at 33 cycles per MFMA, 112 us per layer and 4096 crops = 1.56 PFLOP/s, the chip's sustained rate.  With the
+// side work the steps take 200-260 cycles instead of 134 and the layer 186 us, no better than the two-group kernel's
+// 182-188: the parts placed between the MFMAs are short but are dependent chains (compare -> scalar or -> select -> address
+// -> LDS store), a wave issues in order, and one wave per SIMD has nobody to cover a chain's latency.  What is left to do:
+// branch-free parts (buffer stores, a scratch LDS row) scheduled as independent instruction streams across the gaps.
+constexpr int P64_BM = 256;
+constexpr int P64_THREADS = 256;
+
+template <bool RES>
+__global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a) {
+  constexpr int BM = P64_BM, NT = P64_THREADS;
+  constexpr int NLD = ((BM + 2 * W64_WMAX + 2) * 8 + NT - 1) / NT;   // uint4 slots per thread for one halo range (10)
+  static_assert(NLD == 10, "conv3x3_pipe64_bf16: the k-step schedule below places 10 halo slots");
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+  const int W = a.W, H = a.H;
+  const int rows = BM + 2 * W + 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a_bytes = (rows + 1) * W64_LDA * 2;                    // halo range + the all-zero row (144-byte rows)
+  unsigned char* sW = smem_q;
+  const float* sC = reinterpret_cast<const float*>(smem_q + W64_WBYTES);
+  unsigned char* sA0 = smem_q + W64_WBYTES + W64_CBYTES;
+  const int li = lane & 31, lh = lane >> 5;
+  const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+  const uint16_t* resid = reinterpret_cast<const uint16_t*>(a.residual);
+  uint16_t* out = reinterpret_cast<uint16_t*>(a.out);
+  const int relu_floor = a.relu ? 0 : (int)0x80000000;
+
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+    for (int i = tid; i < W64_WBYTES / 16; i += NT) *reinterpret_cast<uint4*>(sW + 16 * i) = wp[i];
+    float* c = reinterpret_cast<float*>(smem_q + W64_WBYTES);
+    if (tid < 64) {
+      c[tid] = a.bias[tid];
+      c[64 + tid] = a.scale[tid];
+      c[128 + tid] = a.shift[tid];
+    }
+    if (tid < 2 * (W64_LDA * 2 / 16))      // the all-zero row of both buffers
+      *reinterpret_cast<uint4*>(sA0 + (tid / 9) * a_bytes + rows * W64_LDA * 2 + 16 * (tid % 9)) = make_uint4(0, 0, 0, 0);
+  }
+
+  int t0, tstep, tend;
+  tile_walk(a.ntiles, t0, tstep, tend);
+  const int count = t0 < tend ? (tend - t0 + tstep - 1) / tstep : 0;
+
+  // halo range of a tile through a buffer descriptor that covers exactly its rows inside [0, M): zeros outside
+  uint4 areg[NLD];
+  __amdgpu_buffer_rsrc_t a_rs;
+  int a_shift = 0;
+  auto load_a_begin = [&](int tile, bool have) {      // both workgroup-uniform
+    const int gbase = tile * BM - W - 1;
+    const int g_lo = gbase > 0 ? gbase : 0, g_hi = gbase + rows < a.M ? gbase + rows : a.M;
+    a_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(in) + (size_t)g_lo * 64, 0,
+                                             have && g_hi > g_lo ? (g_hi - g_lo) * 128 : 0, 0x00020000);
+    a_shift = (g_lo - gbase) * 128;
+  };
+  auto load_a_one = [&](int k) {
+    areg[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (tid + NT * k) * 16 - a_shift, 0, 0));
+  };
+  auto write_a_one = [&](unsigned char* sA, int k, int nrows) {
+    const int idx = tid + NT * k;
+    if ((idx >> 3) < nrows) *reinterpret_cast<uint4*>(sA + ((idx >> 3) * W64_LDA + 8 * (idx & 7)) * 2) = areg[k];
+  };
+  // byte offset of the lane's operand row per tap (the zero row where padded), for the wave's two 32-pixel row tiles:
+  // the pixels' image coordinates first, then one tap per call, spread over the k-steps
+  int py[2] = {0, 0}, px[2] = {0, 0};
+  bool pin[2] = {false, false};
+  auto arow_begin = [&](int i, int m) {
+    pin[i] = m < a.M;
+    const int rem = m - thin_div(m, H * W, a.mg_hw) * (H * W);
+    py[i] = thin_div(rem, W, a.mg_w);
+    px[i] = rem - py[i] * W;
+  };
+  auto arow_tap = [&](int i, int tap) {
+    const int yy = py[i] + tap / 3 - 1, xx = px[i] + tap % 3 - 1;
+    const bool ok = pin[i] & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+    return ((ok ? wave * 64 + i * 32 + li + (tap / 3) * W + (tap % 3) : rows) * W64_LDA + 8 * lh) * 2;
+  };
+
+  uint2 res[16];
+  int arow[2][9], arow_n[2][9];
+  // piece p = 8i + 4n + g: channels 32n + 8g + 4lh .. + 3 of pixel row m of row tile i:
+  // (acc + bias) * scale + shift (+ residual), ReLU, 4 x bf16.  In three parts, so that each fits between two MFMAs, with
+  // the constants read from LDS one piece ahead.
+  float4 kq[2][3];
+  auto piece_consts = [&](int p) {
+    const float* kc = sC + 32 * ((p >> 2) & 1) + 8 * (p & 3) + 4 * lh;
+    kq[p & 1][0] = *reinterpret_cast<const float4*>(kc);
+    kq[p & 1][1] = *reinterpret_cast<const float4*>(kc + 64);
+    kq[p & 1][2] = *reinterpret_cast<const float4*>(kc + 128);
+  };
+  f32x2 e_lo, e_hi;
+  unsigned e_o0 = 0, e_o1 = 0;
+  auto piece_math = [&](const f32x16 (&ac)[2][2], int p) {
+    const int i = p >> 3, n = (p >> 2) & 1, g = p & 3;
+    const float4 cb = kq[p & 1][0], cs = kq[p & 1][1], ch = kq[p & 1][2];
+    e_lo = __builtin_elementwise_fma((f32x2){ac[i][n][4 * g], ac[i][n][4 * g + 1]} + (f32x2){cb.x, cb.y}, (f32x2){cs.x, cs.y},
+                                     (f32x2){ch.x, ch.y});
+    e_hi = __builtin_elementwise_fma((f32x2){ac[i][n][4 * g + 2], ac[i][n][4 * g + 3]} + (f32x2){cb.z, cb.w}, (f32x2){cs.z, cs.w},
+                                     (f32x2){ch.z, ch.w});
+    if (RES) {
+      const unsigned r0 = res[p].x, r1 = res[p].y;
+      e_lo += (f32x2){__builtin_bit_cast(float, r0 << 16), __builtin_bit_cast(float, r0 & 0xffff0000u)};
+      e_hi += (f32x2){__builtin_bit_cast(float, r1 << 16), __builtin_bit_cast(float, r1 & 0xffff0000u)};
+    }
+  };
+  auto piece_round = [&]() {
+    const thin_i32x2 fl = {relu_floor, relu_floor};
+    const thin_i32x2 li2 = __builtin_elementwise_max(__builtin_bit_cast(thin_i32x2, e_lo), fl);
+    const thin_i32x2 hi2 = __builtin_elementwise_max(__builtin_bit_cast(thin_i32x2, e_hi), fl);
+    e_o0 = __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(thin_f32x2, li2), thin_bf16x2));
+    e_o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(thin_f32x2, hi2), thin_bf16x2));
+  };
+  auto piece_store = [&](int p, int m) {
+    const int c0 = 32 * ((p >> 2) & 1) + 8 * (p & 3) + 4 * lh;
+    if (m < a.M) *reinterpret_cast<uint2*>(out + (size_t)m * 64 + c0) = make_uint2(e_o0, e_o1);
+  };
+  auto epilogue_piece = [&](const f32x16 (&ac)[2][2], int p, int m) {      // all of it at once: the last tile of the walk
+    piece_consts(p);
+    piece_math(ac, p);
+    piece_round();
+    piece_store(p, m);
+  };
+  auto load_res_one = [&](int p, int m) {
+    const int c0 = 32 * ((p >> 2) & 1) + 8 * (p & 3) + 4 * lh;
+    const size_t off = m < a.M ? (size_t)m * 64 + c0 : 0;
+    res[p] = *reinterpret_cast<const uint2*>(resid + off);
+  };
+
+  if (count > 0) {
+    load_a_begin(t0, true);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) load_a_one(k);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) write_a_one(sA0, k, rows);
+    load_a_begin(t0 + tstep, count > 1);
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) load_a_one(k);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      arow_begin(i, t0 * BM + wave * 64 + i * 32 + li);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) arow[i][tap] = arow_tap(i, tap);
+    }
+  }
+  __syncthreads();
+
+  // one tile: MFMAs into ac, the previous tile's epilogue out of ap
+  auto tile_body = [&](f32x16 (&ac)[2][2], const f32x16 (&ap)[2][2], int j) {
+    const int t = t0 + j * tstep;
+    const int mw = t * BM + wave * 64, mw_p = mw - tstep * BM;
+    const unsigned char* sA = sA0 + (j & 1) * a_bytes;
+    unsigned char* sAn = sA0 + ((j + 1) & 1) * a_bytes;
+    const bool have_next = j + 1 < count, have_prev = j > 0;
+    const int rows_next = have_next ? rows : 0;
+    const int m_prev = have_prev ? mw_p + li : 0x7fffff00;      // no previous tile: a row past M, nothing is stored
+    const unsigned char* bl = sW + (lh * 64 + li) * 16;       // + ((tap * 4 + c16) * 2) * 64 * 16 + n * 512
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac[i][n][r] = 0.f;
+    constexpr int NS = 36, D = W64_AHEAD;
+    uint4 av0[D + 1], av1[D + 1], bv0[D + 1], bv1[D + 1];
+    auto rd = [&](int slot, int st) {
+      const int chunk = st / 18, tap = (st % 18) >> 1, c16 = chunk * 2 + (st & 1);
+      av0[slot] = *reinterpret_cast<const uint4*>(sA + arow[0][tap] + c16 * 32);
+      av1[slot] = *reinterpret_cast<const uint4*>(sA + arow[1][tap] + c16 * 32);
+      bv0[slot] = *reinterpret_cast<const uint4*>(bl + (tap * 4 + c16) * 2048);
+      bv1[slot] = *reinterpret_cast<const uint4*>(bl + (tap * 4 + c16) * 2048 + 512);
+    };
+#pragma unroll
+    for (int st = 0; st < D; ++st) rd(st, st);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      if (st == 0) PSTAMP(j, 0);
+      if (st == 5) PSTAMP(j, 3);
+      if (st == 21) PSTAMP(j, 2);
+      if (st == 35) PSTAMP(j, 1);
+      if (st + D < NS) rd((st + D) % (D + 1), st + D);
+      // Side work goes BETWEEN the step's four MFMAs, a part after each: a wave issues in order, so vector instructions
+      // placed after a group of MFMAs only start when the last of them has issued and have one MFMA's shadow, not four.
+      // Nothing below branches (a piece that has nothing to do works on a row past M, an empty range, or unused registers).
+      const int sl = st % (D + 1);
+      auto side = [&](int part) {
+#ifdef P64_NOSIDE
+        return;
+#endif
+        if (st < 5) {                                              // halo range of tile j+1 -> the other buffer
+          if (part == 0) write_a_one(sAn, 2 * st, rows_next);
+          if (part == 2) write_a_one(sAn, 2 * st + 1, rows_next);
+          if (st == 4 && part == 3) piece_consts(0);
+        } else if (st < 5 + 16) {                                  // epilogue of tile j-1, one channel quad per step
+          const int p = st - 5;
+          if (part == 0) piece_math(ap, p);
+          if (part == 1) piece_round();
+          if (part == 2) piece_store(p, m_prev + (p >> 3) * 32);
+          if (part == 3 && p + 1 < 16) piece_consts(p + 1);
+        } else if (st < 26) {                                      // halo range of tile j+2 -> registers
+          if (part == 0) {
+            if (st == 21) load_a_begin(t + 2 * tstep, j + 2 < count);
+            load_a_one(2 * (st - 21));
+          }
+          if (part == 2) load_a_one(2 * (st - 21) + 1);
+        } else if (st == 26) {                                     // border arithmetic of tile j+1
+          if (part == 0) arow_begin(0, mw + tstep * BM + li);
+          if (part == 2) arow_begin(1, mw + tstep * BM + 32 + li);
+        } else {
+          if (part == 0) arow_n[0][st - 27] = arow_tap(0, st - 27);
+          if (part == 2) arow_n[1][st - 27] = arow_tap(1, st - 27);
+        }
+        if (RES && st >= 26 && st < 34) {                          // residual rows of tile j
+          if (part == 1) load_res_one(2 * (st - 26), mw + ((2 * (st - 26)) >> 3) * 32 + li);
+          if (part == 3) load_res_one(2 * (st - 26) + 1, mw + ((2 * (st - 26) + 1) >> 3) * 32 + li);
+        }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      ac[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv0[sl]), __builtin_bit_cast(bf16x8, av0[sl]), ac[0][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      side(0);
+      __builtin_amdgcn_sched_barrier(0);
+      ac[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv1[sl]), __builtin_bit_cast(bf16x8, av0[sl]), ac[0][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      side(1);
+      __builtin_amdgcn_sched_barrier(0);
+      ac[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv0[sl]), __builtin_bit_cast(bf16x8, av1[sl]), ac[1][0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      side(2);
+      __builtin_amdgcn_sched_barrier(0);
+      ac[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bv1[sl]), __builtin_bit_cast(bf16x8, av1[sl]), ac[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      side(3);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) arow[i][tap] = arow_n[i][tap];
+    __syncthreads();
+  };
+
+  f32x16 accA[2][2], accB[2][2];
+  for (int j = 0; j < count; j += 2) {
+    tile_body(accA, accB, j);
+    if (j + 1 < count) tile_body(accB, accA, j + 1);
+  }
+  if (count > 0) {
+    const int mw_l = (t0 + (count - 1) * tstep) * BM + wave * 64;
+    if (count & 1) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) epilogue_piece(accA, p, mw_l + (p >> 3) * 32 + li);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) epilogue_piece(accB, p, mw_l + (p >> 3) * 32 + li);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------ 128 -> 128, weights streamed
 // The 128 -> 128 channel stride-1 3x3 layers of stage 3 (W <= 12) in the same persistent two-group scheme.  Their
 // weights (295 KB) fit neither registers nor LDS and stay where conv3x3s1_halo_bf16 has them: streamed from L2
@@ -850,11 +1125,6 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds32_f32(ThinArgs a) {
 constexpr int P32_BM = 256;
 constexpr int P32_CBYTES = 3 * 32 * 4;
 
-#ifdef UMT_STAMP
-#define PSTAMP(j, k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (j) < 64) g_stamp[threadIdx.x >> 8][j][k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PSTAMP(j, k) do {} while (0)
-#endif
 template <bool RES>
 __global__ __launch_bounds__(512, 1) void conv3x3_pipe32_f32(ThinArgs a) {
   constexpr int BM = P32_BM;
@@ -1328,6 +1598,8 @@ static int grid_for(int ntiles, int per_cu) {
 static size_t thin_lds_bytes(int tm, int w) {
   return 2 * ((((size_t)(128 * tm + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
+static size_t p64_lds_bytes(int w) { return (size_t)W64_WBYTES + W64_CBYTES + 2 * (size_t)(P64_BM + 2 * w + 2 + 1) * W64_LDA * 2; }
+static_assert((size_t)W64_WBYTES + W64_CBYTES + 2 * (size_t)(P64_BM + 2 * W64_WMAX + 2 + 1) * W64_LDA * 2 <= 160 * 1024, "conv3x3_pipe64_bf16: LDS budget");
 static size_t w64_lds_bytes(int w) {
   return (size_t)W64_WBYTES + W64_CBYTES +
          2 * ((((size_t)(W64_BM + 2 * w + 2 + 1) * W64_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
@@ -1385,7 +1657,7 @@ int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int 
   a.ntiles = (int)((M + F32_BM - 1) / F32_BM);
   a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
-  if (!(L.flags & CONV_NO_PIPE32)) {
+  if (!(L.flags & CONV_NO_PIPE32) && M < ((int64_t)1 << 31) - (1 << 20)) {      // (the walk looks one tile step past its last tile)
     a.ntiles = (int)((M + P32_BM - 1) / P32_BM);
     auto kp = residual ? conv3x3_pipe32_f32<true> : conv3x3_pipe32_f32<false>;
     hipLaunchKernelGGL(kp, dim3(grid_for(a.ntiles, 1)), dim3(512), p32_lds_bytes(w), stream, a);
@@ -1408,6 +1680,8 @@ int conv_thin_prepare_device() {      // largest request: W = 48
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_stream128_bf16<true>), s128_lds_bytes(S128_WMAX)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<false>), w64_lds_bytes(W64_WMAX)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_wlds64_bf16<true>), w64_lds_bytes(W64_WMAX)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_pipe64_bf16<false>), p64_lds_bytes(W64_WMAX)));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_pipe64_bf16<true>), p64_lds_bytes(W64_WMAX)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, false>), thin_lds_bytes(UMT_THIN_TM, 48)));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3_thin32_bf16<UMT_THIN_TM, true>), thin_lds_bytes(UMT_THIN_TM, 48)));
   return 0;
@@ -1435,6 +1709,13 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
     a.ntiles = (int)((M + W64_BM - 1) / W64_BM);
     a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
     a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
+    if ((L.flags & CONV_PIPE64) && M < ((int64_t)1 << 31) - (1 << 20)) {      // opt-in: not yet faster than the two-group kernel (see its header)
+      a.ntiles = (int)((M + P64_BM - 1) / P64_BM);
+      auto kp = residual ? conv3x3_pipe64_bf16<true> : conv3x3_pipe64_bf16<false>;
+      hipLaunchKernelGGL(kp, dim3(grid_for(a.ntiles, 1)), dim3(P64_THREADS), p64_lds_bytes(w), stream, a);
+      UMT_CHECK_HIP(hipGetLastError());
+      return 0;
+    }
     auto kern64 = residual ? conv3x3_wlds64_bf16<true> : conv3x3_wlds64_bf16<false>;
     hipLaunchKernelGGL(kern64, dim3(grid_for(a.ntiles, 1)), dim3(512), w64_lds_bytes(w), stream, a);
     UMT_CHECK_HIP(hipGetLastError());
