@@ -245,11 +245,11 @@ def test_fp32_single_role_stage1_kernel_bit_identical_to_two_group_kernel(monkey
 
 @pytest.mark.gpu
 def test_bf16_one_role_64_channel_kernel_bit_identical_to_two_group_kernel(monkeypatch):
-    """bf16 mode, 64 -> 64 layers of stage 2: the opt-in conv3x3_pipe64_bf16 (UMT_CONV_PIPE64=1, read per model handle; one
-    role per wave, 2 x 2 MFMA tiles, operands swapped, 256-pixel tiles, accumulators of consecutive tiles in alternating
-    register sets) against the default conv3x3_wlds64_bf16.  Same k order and epilogue arithmetic: bit-identical features.
-    3 crops leave most workgroups without a tile, 131 leave the last tiles ragged, 900 reach the steady state of the walk
-    (several tiles per workgroup, odd and even counts)."""
+    """bf16 mode, 64 -> 64 layers of stage 2: conv3x3_pipe64_bf16 (one role per wave, 2 x 2 MFMA tiles, operands swapped,
+    256-pixel tiles, accumulators of consecutive tiles in alternating register sets, quads traded between the wave halves
+    for 16-byte stores) against conv3x3_wlds64_bf16 (UMT_CONV_NOPIPE64=1, read per model handle).  Same k order and
+    epilogue arithmetic: bit-identical features.  3 crops leave most workgroups without a tile, 131 leave the last tiles
+    ragged, 900 reach the steady state of the walk (several tiles per workgroup, odd and even counts)."""
     import torch
     from umetrack_amd.lib.models.model_loader import model_from_state_dict
     img = torch.rand(900, 96, 96, generator=torch.Generator().manual_seed(80)).cuda()
@@ -259,7 +259,7 @@ def test_bf16_one_role_64_channel_kernel_bit_identical_to_two_group_kernel(monke
         gm.precision = "bf16"
         return torch.cat([gm.backbone(img[:3]), gm.backbone(img[:131]), gm.backbone(img)]).float().cpu()
 
-    ref = run()
-    monkeypatch.setenv("UMT_CONV_PIPE64", "1")
     got = run()
+    monkeypatch.setenv("UMT_CONV_NOPIPE64", "1")
+    ref = run()
     assert torch.isfinite(got).all() and torch.equal(got, ref)

@@ -183,7 +183,8 @@ int main(int argc, char** argv) {
       ConvLayer L;
       L.taps = sh.taps; L.cin = sh.cin; L.cout = sh.cout; L.cin_s = sh.cin; L.cout_s = sh.cout; L.cout_w = sh.cout;
       L.stride = sh.stride; L.relu = 1;
-      if (getenv("PIPE64")) L.flags |= CONV_PIPE64;      // the experimental one-role 64 -> 64 bf16 kernel
+      if (getenv("NOPIPE64")) L.flags |= CONV_NO_PIPE64;      // the two-group 64 -> 64 bf16 kernel instead of the one-role one
+      if (getenv("NOPIPE32")) L.flags |= CONV_NO_PIPE32;
       const int ho = sh.hw / sh.stride;
       const size_t in_n = (size_t)n * sh.hw * sh.hw * sh.cin, out_n = (size_t)n * ho * ho * sh.cout;
       const size_t w_n = (size_t)sh.taps * sh.cin * sh.cout;

@@ -501,12 +501,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
 // two consecutive tiles alternate between two register sets.  Operands swapped (weights as the row operand): a lane owns
 // 2 x 16 channels of two pixels and stores 8-byte quads, no transposing patch.  k order (32-channel chunk, tap,
 // 16-channel group) and the epilogue arithmetic are conv3x3s1_halo_bf16's: bit-identical.
-// STATUS: opt-in (UMT_CONV_PIPE64=1), not the default.  Its MFMA + LDS loop alone (-DP64_NOSIDE: no side work, wrong
-// results) runs at 33 cycles per MFMA, 112 us per layer and 4096 crops = 1.56 PFLOP/s, the chip's sustained rate.  With the
-// side work the steps take 200-260 cycles instead of 134 and the layer 186 us, no better than the two-group kernel's
-// 182-188: the parts placed between the MFMAs are short but are dependent chains (compare -> scalar or -> select -> address
-// -> LDS store), a wave issues in order, and one wave per SIMD has nobody to cover a chain's latency.  What is left to do:
-// branch-free parts (buffer stores, a scratch LDS row) scheduled as independent instruction streams across the gaps.
+// Measured (tools/conv_bench.hip, 4096 crops, random data): the MFMA + LDS loop alone (-DP64_NOSIDE: no side work, wrong
+// results) runs at 33 cycles per MFMA, 112 us per layer = 1.56 PFLOP/s, the chip's sustained rate; with one kind of side work
+// at a time (-DP64_SIDE_MASK) halo stores cost +14 us, halo loads +9, border arithmetic +18, the epilogue +50 of which 38 were
+// its 8-byte stores (hence the quad trade below).  All of it: 169 us without and 203 us with a residual against 185 / 208 for
+// the two-group kernel; in the bf16 bench 0.62-0.67 / 0.76-0.84 ms per layer and 16 384 crops against 0.70-0.81 / 0.80-0.90.
+// The side-work steps still take 170-300 cycles instead of 134: the parts between the MFMAs are short but are dependent
+// chains, a wave issues in order, and one wave per SIMD has nobody to cover a chain's latency.
 constexpr int P64_BM = 256;
 constexpr int P64_THREADS = 256;
 
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
   const int W = a.W, H = a.H;
   const int rows = BM + 2 * W + 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int a_bytes = (rows + 1) * W64_LDA * 2;                    // halo range + the all-zero row (144-byte rows)
+  const int a_bytes = (rows + 2) * W64_LDA * 2;                    // halo range + the all-zero row + a scratch row (144-byte rows)
   unsigned char* sW = smem_q;
   const float* sC = reinterpret_cast<const float*>(smem_q + W64_WBYTES);
   unsigned char* sA0 = smem_q + W64_WBYTES + W64_CBYTES;
@@ -561,31 +562,45 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
   auto load_a_one = [&](int k) {
     areg[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (tid + NT * k) * 16 - a_shift, 0, 0));
   };
+  // (slots past the range's last row, and every slot when there is no next tile, go to the scratch row: no branch, no
+  // exec mask change between two MFMAs)
+  const int wa_base = ((tid >> 3) * W64_LDA + 8 * (tid & 7)) * 2, wa_scratch = ((rows + 1) * W64_LDA + 8 * (tid & 7)) * 2;
   auto write_a_one = [&](unsigned char* sA, int k, int nrows) {
-    const int idx = tid + NT * k;
-    if ((idx >> 3) < nrows) *reinterpret_cast<uint4*>(sA + ((idx >> 3) * W64_LDA + 8 * (idx & 7)) * 2) = areg[k];
+    const int off = (tid >> 3) + (NT >> 3) * k < nrows ? wa_base + k * (NT >> 3) * W64_LDA * 2 : wa_scratch;
+    *reinterpret_cast<uint4*>(sA + off) = areg[k];
   };
-  // byte offset of the lane's operand row per tap (the zero row where padded), for the wave's two 32-pixel row tiles:
-  // the pixels' image coordinates first, then one tap per call, spread over the k-steps
-  int py[2] = {0, 0}, px[2] = {0, 0};
-  bool pin[2] = {false, false};
+  // byte offset of the lane's operand row per tap (the zero row where padded), for the wave's two 32-pixel row tiles: a
+  // 9-bit mask of the taps inside the image from the pixel's coordinates first, then one select per tap, spread over
+  // the k-steps (the empty asm statements keep each result in a register where it is computed: left alone the compiler
+  // holds the comparisons in scalar registers and does the selects at the top of the next tile, in front of its first reads)
+  unsigned bmask[2] = {0, 0};
+  const int zero_off = (rows * W64_LDA + 8 * lh) * 2;
   auto arow_begin = [&](int i, int m) {
-    pin[i] = m < a.M;
     const int rem = m - thin_div(m, H * W, a.mg_hw) * (H * W);
-    py[i] = thin_div(rem, W, a.mg_w);
-    px[i] = rem - py[i] * W;
+    const int y = thin_div(rem, W, a.mg_w), x = rem - y * W;
+    unsigned mk = m < a.M ? 0x1ffu : 0u;
+    mk &= y == 0 ? ~0x007u : ~0u;
+    mk &= y == H - 1 ? ~0x1c0u : ~0u;
+    mk &= x == 0 ? ~0x049u : ~0u;
+    mk &= x == W - 1 ? ~0x124u : ~0u;
+    asm volatile("" : "+v"(mk));
+    bmask[i] = mk;
   };
   auto arow_tap = [&](int i, int tap) {
-    const int yy = py[i] + tap / 3 - 1, xx = px[i] + tap % 3 - 1;
-    const bool ok = pin[i] & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-    return ((ok ? wave * 64 + i * 32 + li + (tap / 3) * W + (tap % 3) : rows) * W64_LDA + 8 * lh) * 2;
+    int r = (bmask[i] >> tap) & 1u ? ((wave * 64 + i * 32 + li + (tap / 3) * W + (tap % 3)) * W64_LDA + 8 * lh) * 2 : zero_off;
+    asm volatile("" : "+v"(r));
+    return r;
   };
 
-  uint2 res[16];
+  uint4 res4[8];
   int arow[2][9], arow_n[2][9];
-  // piece p = 8i + 4n + g: channels 32n + 8g + 4lh .. + 3 of pixel row m of row tile i:
-  // (acc + bias) * scale + shift (+ residual), ReLU, 4 x bf16.  In three parts, so that each fits between two MFMAs, with
-  // the constants read from LDS one piece ahead.
+  // piece p = 8i + 4n + g: channels 32n + 8g + 4lh .. + 3 (a "quad") of pixel row m of row tile i:
+  // (acc + bias) * scale + shift (+ residual), ReLU, 4 x bf16.  In parts, so that each fits between two MFMAs, with the
+  // constants read from LDS one piece ahead.  A lane's quads are 8 bytes every 16: stored as they are (8 bytes per lane, 16
+  // per pixel row and instruction) the stores alone cost 38 us of a 186 us layer.  So an even quad waits for the odd one
+  // after it, the two halves of the wave trade one quad each (v_permlane32_swap: lanes 32-63 of the first operand against
+  // lanes 0-31 of the second), and every lane stores 16 bytes, 32 per pixel row and instruction.  The residual is loaded in
+  // that traded layout and traded back by the same swap.
   float4 kq[2][3];
   auto piece_consts = [&](int p) {
     const float* kc = sC + 32 * ((p >> 2) & 1) + 8 * (p & 3) + 4 * lh;
@@ -594,7 +609,7 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
     kq[p & 1][2] = *reinterpret_cast<const float4*>(kc + 128);
   };
   f32x2 e_lo, e_hi;
-  unsigned e_o0 = 0, e_o1 = 0;
+  unsigned e_o0 = 0, e_o1 = 0, s_o0 = 0, s_o1 = 0, r_od0 = 0, r_od1 = 0;
   auto piece_math = [&](const f32x16 (&ac)[2][2], int p) {
     const int i = p >> 3, n = (p >> 2) & 1, g = p & 3;
     const float4 cb = kq[p & 1][0], cs = kq[p & 1][1], ch = kq[p & 1][2];
@@ -603,32 +618,50 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
     e_hi = __builtin_elementwise_fma((f32x2){ac[i][n][4 * g + 2], ac[i][n][4 * g + 3]} + (f32x2){cb.z, cb.w}, (f32x2){cs.z, cs.w},
                                      (f32x2){ch.z, ch.w});
     if (RES) {
-      const unsigned r0 = res[p].x, r1 = res[p].y;
+      unsigned r0, r1;
+      if (!(p & 1)) {
+        const uint4 r = res4[p >> 1];
+        const auto w0 = __builtin_amdgcn_permlane32_swap(r.x, r.z, false, false);
+        const auto w1 = __builtin_amdgcn_permlane32_swap(r.y, r.w, false, false);
+        r0 = w0[0]; r1 = w1[0];
+        r_od0 = w0[1]; r_od1 = w1[1];
+      } else {
+        r0 = r_od0; r1 = r_od1;
+      }
       e_lo += (f32x2){__builtin_bit_cast(float, r0 << 16), __builtin_bit_cast(float, r0 & 0xffff0000u)};
       e_hi += (f32x2){__builtin_bit_cast(float, r1 << 16), __builtin_bit_cast(float, r1 & 0xffff0000u)};
     }
   };
-  auto piece_round = [&]() {
+  auto piece_round = [&](int p) {
     const thin_i32x2 fl = {relu_floor, relu_floor};
     const thin_i32x2 li2 = __builtin_elementwise_max(__builtin_bit_cast(thin_i32x2, e_lo), fl);
     const thin_i32x2 hi2 = __builtin_elementwise_max(__builtin_bit_cast(thin_i32x2, e_hi), fl);
     e_o0 = __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(thin_f32x2, li2), thin_bf16x2));
     e_o1 = __builtin_bit_cast(unsigned, __builtin_convertvector(__builtin_bit_cast(thin_f32x2, hi2), thin_bf16x2));
+    if (!(p & 1)) { s_o0 = e_o0; s_o1 = e_o1; }
   };
-  auto piece_store = [&](int p, int m) {
-    const int c0 = 32 * ((p >> 2) & 1) + 8 * (p & 3) + 4 * lh;
-    if (m < a.M) *reinterpret_cast<uint2*>(out + (size_t)m * 64 + c0) = make_uint2(e_o0, e_o1);
+  auto piece_store = [&](int p, int m) {      // odd pieces only: the quad before it and this one
+    if (!(p & 1)) return;
+    const int c0 = 32 * ((p >> 2) & 1) + 8 * ((p & 2) + lh);
+    const auto w0 = __builtin_amdgcn_permlane32_swap(s_o0, e_o0, false, false);
+    const auto w1 = __builtin_amdgcn_permlane32_swap(s_o1, e_o1, false, false);
+#ifdef P64_NOSTORE
+    if (m < 0)
+#else
+    if (m < a.M)
+#endif
+      *reinterpret_cast<uint4*>(out + (size_t)m * 64 + c0) = make_uint4(w0[0], w1[0], w0[1], w1[1]);
   };
   auto epilogue_piece = [&](const f32x16 (&ac)[2][2], int p, int m) {      // all of it at once: the last tile of the walk
     piece_consts(p);
     piece_math(ac, p);
-    piece_round();
+    piece_round(p);
     piece_store(p, m);
   };
-  auto load_res_one = [&](int p, int m) {
-    const int c0 = 32 * ((p >> 2) & 1) + 8 * (p & 3) + 4 * lh;
+  auto load_res_one = [&](int q, int m) {      // quads 2q and 2q + 1, in the traded layout
+    const int c0 = 32 * ((q >> 1) & 1) + 16 * (q & 1) + 8 * lh;
     const size_t off = m < a.M ? (size_t)m * 64 + c0 : 0;
-    res[p] = *reinterpret_cast<const uint2*>(resid + off);
+    res4[q] = *reinterpret_cast<const uint4*>(resid + off);
   };
 
   if (count > 0) {
@@ -688,8 +721,11 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
       // Nothing below branches (a piece that has nothing to do works on a row past M, an empty range, or unused registers).
       const int sl = st % (D + 1);
       auto side = [&](int part) {
-#ifdef P64_NOSIDE
+#ifdef P64_NOSIDE      // diagnostic builds (wrong results): no side work at all, or with P64_SIDE_MASK only some of it
         return;
+#endif
+#ifdef P64_SIDE_MASK   // bit 0: halo stores, 1: epilogue, 2: halo loads, 3: border arithmetic (+ residual loads)
+        if (!((P64_SIDE_MASK >> (st < 5 ? 0 : st < 21 ? 1 : st < 26 ? 2 : 3)) & 1)) return;
 #endif
         if (st < 5) {                                              // halo range of tile j+1 -> the other buffer
           if (part == 0) write_a_one(sAn, 2 * st, rows_next);
@@ -698,7 +734,7 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
         } else if (st < 5 + 16) {                                  // epilogue of tile j-1, one channel quad per step
           const int p = st - 5;
           if (part == 0) piece_math(ap, p);
-          if (part == 1) piece_round();
+          if (part == 1) piece_round(p);
           if (part == 2) piece_store(p, m_prev + (p >> 3) * 32);
           if (part == 3 && p + 1 < 16) piece_consts(p + 1);
         } else if (st < 26) {                                      // halo range of tile j+2 -> registers
@@ -715,8 +751,7 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
           if (part == 2) arow_n[1][st - 27] = arow_tap(1, st - 27);
         }
         if (RES && st >= 26 && st < 34) {                          // residual rows of tile j
-          if (part == 1) load_res_one(2 * (st - 26), mw + ((2 * (st - 26)) >> 3) * 32 + li);
-          if (part == 3) load_res_one(2 * (st - 26) + 1, mw + ((2 * (st - 26) + 1) >> 3) * 32 + li);
+          if (part == 1) load_res_one(st - 26, mw + ((st - 26) >> 2) * 32 + li);
         }
       };
       __builtin_amdgcn_sched_barrier(0);
@@ -1598,8 +1633,8 @@ static int grid_for(int ntiles, int per_cu) {
 static size_t thin_lds_bytes(int tm, int w) {
   return 2 * ((((size_t)(128 * tm + 2 * w + 2 + 1) * T_LDH * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
 }
-static size_t p64_lds_bytes(int w) { return (size_t)W64_WBYTES + W64_CBYTES + 2 * (size_t)(P64_BM + 2 * w + 2 + 1) * W64_LDA * 2; }
-static_assert((size_t)W64_WBYTES + W64_CBYTES + 2 * (size_t)(P64_BM + 2 * W64_WMAX + 2 + 1) * W64_LDA * 2 <= 160 * 1024, "conv3x3_pipe64_bf16: LDS budget");
+static size_t p64_lds_bytes(int w) { return (size_t)W64_WBYTES + W64_CBYTES + 2 * (size_t)(P64_BM + 2 * w + 2 + 2) * W64_LDA * 2; }
+static_assert((size_t)W64_WBYTES + W64_CBYTES + 2 * (size_t)(P64_BM + 2 * W64_WMAX + 2 + 2) * W64_LDA * 2 <= 160 * 1024, "conv3x3_pipe64_bf16: LDS budget");
 static size_t w64_lds_bytes(int w) {
   return (size_t)W64_WBYTES + W64_CBYTES +
          2 * ((((size_t)(W64_BM + 2 * w + 2 + 1) * W64_LDA * 2 + 15) & ~(size_t)15) + 4 * 32 * T_LDP * sizeof(float));
@@ -1709,7 +1744,7 @@ int launch_conv_thin_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, 
     a.ntiles = (int)((M + W64_BM - 1) / W64_BM);
     a.mg_hw = (unsigned)(((uint64_t)1 << 32) / (uint64_t)(h * w)) + 1u;
     a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
-    if ((L.flags & CONV_PIPE64) && M < ((int64_t)1 << 31) - (1 << 20)) {      // opt-in: not yet faster than the two-group kernel (see its header)
+    if (!(L.flags & CONV_NO_PIPE64) && M < ((int64_t)1 << 31) - (1 << 20)) {      // (the walk looks one tile step past its last tile)
       a.ntiles = (int)((M + P64_BM - 1) / P64_BM);
       auto kp = residual ? conv3x3_pipe64_bf16<true> : conv3x3_pipe64_bf16<false>;
       hipLaunchKernelGGL(kp, dim3(grid_for(a.ntiles, 1)), dim3(P64_THREADS), p64_lds_bytes(w), stream, a);

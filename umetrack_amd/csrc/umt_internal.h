@@ -60,7 +60,7 @@ enum : unsigned {
   CONV_NO_S2 = 32u,         // UMT_CONV_NOS2: no fused stride-2 + down-sample kernel
   CONV_X3_NO_S2 = 64u,      // UMT_X3_NOS2
   CONV_NO_CHAIN = 256u,     // UMT_CONV_NOCHAIN: the head's 1x1 chains as three conv_igemm_f32 launches instead of conv_chain.hip
-  CONV_PIPE64 = 2048u,      // UMT_CONV_PIPE64: bf16 64 -> 64 layers on conv3x3_pipe64_bf16 (experimental) instead of conv3x3_wlds64_bf16
+  CONV_NO_PIPE64 = 2048u,   // UMT_CONV_NOPIPE64: bf16 64 -> 64 layers on the two-group conv3x3_wlds64_bf16 instead of conv3x3_pipe64_bf16
   CONV_NO_PIPE32 = 1024u,   // UMT_CONV_NOPIPE32: fp32 stage 1 on the two-group conv3x3_wlds32_f32 instead of conv3x3_pipe32_f32
   CONV_NO_S2P = 512u,       // UMT_CONV_NOS2P: fp32 fused stride-2 layers on the one-tile-per-workgroup kernel instead of the persistent one
   CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
