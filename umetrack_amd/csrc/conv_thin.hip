@@ -504,8 +504,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wlds64_bf16(ThinArgs a) {
 // Measured (tools/conv_bench.hip, 4096 crops, random data): the MFMA + LDS loop alone (-DP64_NOSIDE: no side work, wrong
 // results) runs at 33 cycles per MFMA, 112 us per layer = 1.56 PFLOP/s, the chip's sustained rate; with one kind of side work
 // at a time (-DP64_SIDE_MASK) halo stores cost +14 us, halo loads +9, border arithmetic +18, the epilogue +50 of which 38 were
-// its 8-byte stores (hence the quad trade below).  All of it: 169 us without and 203 us with a residual against 185 / 208 for
-// the two-group kernel; in the bf16 bench 0.62-0.67 / 0.76-0.84 ms per layer and 16 384 crops against 0.70-0.81 / 0.80-0.90.
+// its 8-byte stores (hence the quad trade below).  All of it: 172 us without and 190 us with a residual (906 MB: 4.8 TB/s, the
+// HBM floor of that layer) against 185 / 208 for the two-group kernel; in the bf16 bench 0.62-0.67 / 0.76-0.84 ms per layer and
+// 16 384 crops against 0.70-0.81 / 0.80-0.90.  Operand prefetch depth (W64_AHEAD 1, 2, 3) makes no difference.
 // The side-work steps still take 170-300 cycles instead of 134: the parts between the MFMAs are short but are dependent
 // chains, a wave issues in order, and one wave per SIMD has nobody to cover a chain's latency.
 constexpr int P64_BM = 256;
@@ -712,8 +713,8 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
       if (st == 0) PSTAMP(j, 0);
-      if (st == 5) PSTAMP(j, 3);
-      if (st == 21) PSTAMP(j, 2);
+      if (st == 10) PSTAMP(j, 3);
+      if (st == 26) PSTAMP(j, 2);
       if (st == 35) PSTAMP(j, 1);
       if (st + D < NS) rd((st + D) % (D + 1), st + D);
       // Side work goes BETWEEN the step's four MFMAs, a part after each: a wave issues in order, so vector instructions
@@ -725,24 +726,24 @@ __global__ __launch_bounds__(P64_THREADS, 1) void conv3x3_pipe64_bf16(ThinArgs a
         return;
 #endif
 #ifdef P64_SIDE_MASK   // bit 0: halo stores, 1: epilogue, 2: halo loads, 3: border arithmetic (+ residual loads)
-        if (!((P64_SIDE_MASK >> (st < 5 ? 0 : st < 21 ? 1 : st < 26 ? 2 : 3)) & 1)) return;
+        if (!((P64_SIDE_MASK >> (st < 5 ? 0 : st < 10 ? 2 : st < 26 ? 1 : 3)) & 1)) return;
 #endif
         if (st < 5) {                                              // halo range of tile j+1 -> the other buffer
           if (part == 0) write_a_one(sAn, 2 * st, rows_next);
           if (part == 2) write_a_one(sAn, 2 * st + 1, rows_next);
-          if (st == 4 && part == 3) piece_consts(0);
-        } else if (st < 5 + 16) {                                  // epilogue of tile j-1, one channel quad per step
-          const int p = st - 5;
+        } else if (st < 10) {                                      // halo range of tile j+2 -> registers, as early as the
+          if (part == 0) {                                         // registers are free: it is stored at the top of the next
+            if (st == 5) load_a_begin(t + 2 * tstep, j + 2 < count);   // tile, 30 k-steps from here (an HBM round trip under
+            load_a_one(2 * (st - 5));                              // load is 10-15 of them)
+          }
+          if (part == 2) load_a_one(2 * (st - 5) + 1);
+          if (st == 9 && part == 3) piece_consts(0);
+        } else if (st < 10 + 16) {                                 // epilogue of tile j-1, one channel quad per step
+          const int p = st - 10;
           if (part == 0) piece_math(ap, p);
           if (part == 1) piece_round(p);
           if (part == 2) piece_store(p, m_prev + (p >> 3) * 32);
           if (part == 3 && p + 1 < 16) piece_consts(p + 1);
-        } else if (st < 26) {                                      // halo range of tile j+2 -> registers
-          if (part == 0) {
-            if (st == 21) load_a_begin(t + 2 * tstep, j + 2 < count);
-            load_a_one(2 * (st - 21));
-          }
-          if (part == 2) load_a_one(2 * (st - 21) + 1);
         } else if (st == 26) {                                     // border arithmetic of tile j+1
           if (part == 0) arow_begin(0, mw + tstep * BM + li);
           if (part == 2) arow_begin(1, mw + tstep * BM + 32 + li);
