@@ -525,7 +525,7 @@ def main():
                                   "frac": hbm_achieved / HBM_PEAK_GBS,
                                   "note": "same launches priced by bytes: unfused input+output(+residual) rows of every "
                                           "backbone launch; the bf16 backbone sits between the two rooflines"},
-                     "kernel": "backbone: stem + 24 " + {"bf16": "conv_*_bf16", "fp32": "conv_igemm_f32 / conv3x3s1_halo_f32 / conv3x3s2p_ds_f32 / conv3x3_wlds32_f32",
+                     "kernel": "backbone: stem + 24 " + {"bf16": "conv_*_bf16", "fp32": "conv_igemm_f32 / conv3x3s1_halo_f32 / conv3x3s2p_ds_f32 / conv3x3_pipe32_f32",
                                                           "fp32x3": "conv3x3s1_halo_x3 / conv3x3s2_ds_x3 (+ conv3x3s2p_ds_f32, conv_igemm_f32)"}[args.precision]
                                + " launches per forward call",
                      "flop_per_launch": BACKBONE_FLOP_PER_CROP * crops_per_call, "avg_ms": bb_ms / calls,
