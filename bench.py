@@ -264,6 +264,63 @@ def cpu_baseline(pipe, n_hands, budget_s=12.0):
                                f"({cores} torch threads), bounded to about {budget_s:.0f} s in all"}}, pred, mpjpe
 
 
+def per_frame_row(pipe, n_frames=256):
+    """The reference's own call pattern (tracker.py:141-168, run_eval_known_skeleton.py:68-89): one
+    HandTracker.track_frame per frame (1 frame = 2 hands = 4 crops, temporal memory on after the first frame) and
+    landmarks_from_hand_pose per hand, on the first frames of the same workload; host images and camera objects as
+    the stream reader delivers them.  The GPU row beside cpu_baseline.matrix.end_to_end_batch2."""
+    from umetrack_amd.lib.common import camera
+    from umetrack_amd.lib.tracker.perspective_crop import landmarks_from_hand_pose
+    from umetrack_amd.lib.tracker.tracker import HandTracker, HandTrackerOpts, InputFrame, ViewData
+    wl = pipe.wl
+    T, W, H, V = wl.T, synthetic.SRC_W, synthetic.SRC_H, synthetic.N_VIEWS
+    n_frames = min(n_frames, wl.n_rec * T)
+    frames = pipe.images[:n_frames * W * H * V].cpu().numpy().reshape(n_frames, H, V, W)
+    rig = [camera.Fisheye62CameraModel(W, H, (r[2], r[3]), (r[4], r[5]), list(r[6:14]), r[14:].reshape(4, 4).copy())
+           for r in wl.rig_cams]
+    work = []
+    for f in range(n_frames):
+        rec, t = divmod(f, T)
+        crop_cams = {}
+        for hand in range(2):
+            s = (rec * 2 + hand) * T + t
+            crop_cams[hand] = {int(wl.views[s, v]): camera.PinholePlaneCameraModel(
+                96, 96, tuple(wl.dst_cams[2 * s + v, 0:2]), tuple(wl.dst_cams[2 * s + v, 2:4]), (),
+                wl.dst_cams[2 * s + v, 4:].reshape(4, 4).copy()) for v in range(2)}
+        views = [ViewData(image=frames[f, :, v, :], camera=rig[v], camera_angle=0.0) for v in range(V)]
+        work.append((InputFrame(views=views), crop_cams))
+    pipe.model.reset_memory()
+    tracker = HandTracker(pipe.model, HandTrackerOpts())
+    lm = np.zeros((n_frames, 2, 21, 3), np.float32)
+
+    def run(lo, hi):
+        for f in range(lo, hi):
+            if f % T == 0:
+                tracker.reset_history()            # a new recording starts without memory
+            res = tracker.track_frame(work[f][0], pipe.hm, work[f][1])
+            for hand, pose in res.hand_poses.items():
+                lm[f, hand] = landmarks_from_hand_pose(pipe.hm, pose, hand)
+
+    warm = min(8, n_frames)
+    run(0, warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(0, n_frames)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the same frames through the bulk path's landmarks are not comparable (use_memory differs); check finiteness and
+    # report the distance to ground truth instead
+    gt = pipe.gt_lm.view(wl.n_rec, 2, T, 21, 3)[:(n_frames + T - 1) // T].permute(0, 2, 1, 3, 4).reshape(-1, 2, 21, 3)[:n_frames]
+    return {"value": 2 * n_frames / dt, "unit": "hand-frames/s", "ms_per_frame": dt / n_frames * 1e3, "frames": n_frames,
+            "hands_per_frame": 2, "crops_per_frame": 4, "finite": bool(np.isfinite(lm).all()),
+            "mpjpe_vs_gt_mm": float(np.linalg.norm(lm - gt.cpu().numpy(), axis=-1).mean()),
+            "host_syncs_per_frame": 1,
+            "what": "HandTracker.track_frame + landmarks_from_hand_pose per hand, frame by frame, host uint8 views in, numpy "
+                    "poses and landmarks out, temporal memory on after each recording's first frame; one pinned H2D copy, "
+                    "warp + network + FK, one D2H copy and one stream synchronisation per frame (crop cameras given, as "
+                    "in cpu_baseline.matrix.end_to_end_batch2)"}
+
+
 def stage_rows(stage_ms, pipe, backbone_ms, forward_ms, mfma_peak):
     """every stage of one step with its algorithmic bytes or FLOP, its HIP-event time and the
     fraction of the roofline that bounds it.  Times other than the head's are from one extra step after the timed
@@ -305,10 +362,14 @@ def stream_main(args, rank, world, dev):
     runner.run(min(args.stream_frames, args.frames * world), rank, world)          # warm-up: one chunk per rank
     for _ in range(max(args.warmup - 1, 0)):
         runner.run(args.stream_frames, rank, world)
-    elapsed, res = 0.0, None
+    elapsed, res, lo, hi = 0.0, None, 0.0, 0.0
+    cdev = dev if (world > 1 and torch.distributed.get_backend() == "nccl") else None
     for _ in range(args.steps):
         res = runner.run(args.stream_frames, rank, world)
-        elapsed += udist.max_over_ranks(res.seconds, dev if world > 1 else None)
+        elapsed += udist.max_over_ranks(res.seconds, cdev)
+        a, b = udist.min_max_over_ranks(res.seconds * 1e3, cdev)
+        lo, hi = lo + a, hi + b
+    collective = udist.describe(cdev)
     fin = mu.finalize_partials(res.partials)
     if rank != 0:
         return
@@ -322,6 +383,7 @@ def stream_main(args, rank, world, dev):
                                "one all-reduce of the 108 float64 metric partials; the time includes generating the stream",
                    "stream_frames": args.stream_frames, "chunk_frames": args.frames,
                    "chunks_rank0": list(res.chunks_local), "weights": "seeded random (pretrained_weights.torch not distributed)"},
+        "collective": dict(collective, ms_per_step_min_rank=lo / args.steps, ms_per_step_max_rank=hi / args.steps),
         "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa, "n_valid": fin.n_valid, "n_total": fin.n_total}))
 
 
@@ -354,6 +416,8 @@ def main():
     ap.add_argument("--stream-frames", type=int, default=0,
                     help="run BASELINE.json configs[4] instead: a synthetic stream of this many frames, produced on the "
                          "device in chunks of --frames, sharded over the ranks by contiguous chunk (STRONG scaling)")
+    ap.add_argument("--per-frame-frames", type=int, default=256,
+                    help="frames of the per-frame tracker row (HandTracker.track_frame, 2 hands x 2 views per call; 0 = skip)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host->device copy-rate measurement")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
@@ -389,7 +453,11 @@ def main():
         pipe.step()
     torch.cuda.synchronize()
     udist.barrier()
-    elapsed = udist.max_over_ranks(time.perf_counter() - t0, dev if world > 1 else None)
+    local_elapsed = time.perf_counter() - t0
+    cdev = dev if (world > 1 and torch.distributed.get_backend() == "nccl") else None    # gloo reduces host tensors
+    elapsed = udist.max_over_ranks(local_elapsed, cdev)
+    rank_ms = udist.min_max_over_ranks(local_elapsed / args.steps * 1e3, cdev)
+    collective = udist.describe(cdev)
     progress(rank, f"timed region done: {elapsed / args.steps * 1e3:.2f} ms per step (max over ranks)")
     bb_ms, fwd_ms, calls = pipe.model.timing_read()
     pipe.model.timing_enable(False)
@@ -473,18 +541,21 @@ def main():
         stage_ms[name] = stage_ms.get(name, 0.0) + e0.elapsed_time(e1)
 
     rec_dt, rec_fin = time_recurrent()
+    progress(rank, "per-frame tracker path")
+    per_frame = per_frame_row(pipe, args.per_frame_frames) if args.per_frame_frames > 0 and rank == 0 else None
 
     hands_per_step = pipe.S * world
     if rank != 0:
         return
     crops_per_call = 2 * pipe.chunk
     bf16 = args.precision == "bf16"
-    traffic = None
+    traffic = traffic_head = None
     tpath = next((q for q in (os.path.join(ROOT, "profiles", f"r{r:02d}_backbone_traffic.json") for r in (3, 2, 1))
                   if os.path.exists(q)), "")
     if tpath:      # PMC passes cannot run inside this process; see the file for provenance
         with open(tpath) as fh:
             tj = json.load(fh)
+        traffic_head = tj.get("measured_at_head")
         tj = tj.get(args.precision, tj if not bf16 else {})
         if "read_bytes_per_crop" in tj:
             traffic = (tj["read_bytes_per_crop"] + tj["write_bytes_per_crop"]) * crops_per_call
@@ -518,6 +589,7 @@ def main():
                    "parallelism": f"frames sharded over {world} GPU(s); all-reduce of 108 float64 metric partials"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "peak_note": peak_note, "traffic": traffic,
+                     "traffic_measured_at_head": traffic_head,
                      "traffic_note": "HBM bytes per forward call from rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
                                      f"profiles/{os.path.basename(tpath)} (separate --pmc passes of tools/round_profiles.sh; r02 on: measured at "
                                      "16384 crops per forward call, the size of this run's calls)",
@@ -541,10 +613,15 @@ def main():
         "stages": stage_rows(stage_ms, pipe, bb_ms / calls, fwd_ms / calls, peak),
         "model_tflops": MODEL_FLOP_PER_HAND * pipe.S * args.steps / elapsed / 1e12,
         "mpjpe_mm": fin.mpjpe, "mpjpa": fin.mpjpa,
+        "collective": dict(collective, ms_per_step_min_rank=rank_ms[0], ms_per_step_max_rank=rank_ms[1],
+                           note="all-reduce(sum) of the 108 float64 metric partials, once per step; allreduce_us = mean of "
+                                "20 timed calls (slowest rank); ms_per_step_* = each rank's own clock over the timed region"),
         "recurrent": {"value_per_gpu": pipe.S / rec_dt, "unit": "hand-frames/s", "ms_per_step": rec_dt * 1e3,
                       "note": f"{pipe.wl.n_rec} recordings x {pipe.wl.T} frames in lock-step, use_memory=True after "
                               "frame 0, rank 0 only, 1 timed pass", "mpjpe_mm": rec_fin.mpjpe},
     }
+    if per_frame is not None:
+        line["per_frame"] = per_frame
     progress(rank, "host-to-device copy measurements")
     if not args.no_pcie:
         rate = h2d_rate_gbs(dev)

@@ -54,7 +54,7 @@ enum { UMT_WARP_NO_DEPTH_CHECK = 0x100 };
 
 const char* umt_last_error(void);
 /* bumped on every signature change; bindings compare it with the value they were written for */
-#define UMT_ABI_VERSION 2
+#define UMT_ABI_VERSION 3
 int umt_abi_version(void);
 
 /* Conditions a kernel can detect but an asynchronous call cannot return: the kernels OR these bits into a status
@@ -94,6 +94,10 @@ int umt_model_clear_memory(umt_model* m);                              /* back t
 int umt_model_read_memory(const umt_model* m, float* mem_dev, float* prev_ext_dev, void* stream);
 /* copies the UMT_STATUS_* word to *status_host (host memory), optionally clears it, and waits for `stream` */
 int umt_model_status(umt_model* m, int32_t* status_host, int clear, void* stream);
+/* the same word copied to DEVICE memory (status_dev, int32[1]) on `stream`, optionally cleared, without waiting: a caller
+ * that brings its outputs to the host in one copy anyway (HandTracker._finish, replacing the per-tensor copies of
+ * lib/tracker/tracker.py:156-161) puts the word next to them and pays no extra synchronisation */
+int umt_model_status_async(umt_model* m, int32_t* status_dev, int clear, void* stream);
 
 /* ---- workspace sizes (bytes) ---- */
 int64_t umt_backbone_workspace_bytes(int n_crops);

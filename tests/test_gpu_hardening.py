@@ -105,8 +105,13 @@ def test_out_of_range_indices_and_nan_inputs_are_flagged():
     out = m.regress_pose_use_skeleton(fd, _desc(sr, [0, 1], [False, False]), skel)
     assert torch.isfinite(out.joint_angles[0]).all() and torch.isnan(out.joint_angles[1]).all()
     assert torch.isnan(out.wrist_xfs[1]).all() and torch.isnan(out.landmark_uncertainty_sigmas[1]).all()
+    # the reference returns such a NaN row and carries on: the status bit is set, check_status() reports it
+    # without raising unless asked to
+    assert m.status(clear=False) == nat.STATUS_NONFINITE_OUTPUT
     with pytest.raises(nat.UmtError, match="not finite"):
-        m.check_status()
+        m.check_status(raise_nonfinite=True)
+    m.regress_pose_use_skeleton(fd, _desc(sr, [0, 1], [False, False]), skel)
+    assert m.check_status() == nat.STATUS_NONFINITE_OUTPUT and m.status() == 0
     # malformed sample_range
     bad = sr.clone()
     bad[1, 1] = 9

@@ -91,6 +91,66 @@ def test_tracker_frames_match_oracle(hand_model_np):
     assert empty.hand_poses == {} and not tracker._valid_tracking_history.any()
 
 
+def test_track_frame_one_host_sync_and_cached_landmarks(monkeypatch):
+    """a frame costs ONE host synchronisation.  After a warm-up frame (allocations, memory rows)
+    track_frame runs with torch's sync debug mode set to "error" - any pageable copy, .item() or .cpu() raises -
+    and the explicit stream synchronisations are counted.  The landmarks the result carries equal those of the
+    generic landmarks_from_hand_pose round trip."""
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.tracker.perspective_crop import landmarks_from_hand_pose
+    from umetrack_amd.lib.tracker.tracker import HandTracker, HandTrackerOpts, InputFrame, ViewData
+    from umetrack_amd.lib.tracker.tracking_result import SingleHandPose
+    rng = np.random.default_rng(23)
+    hm = load_generic_hand_model()
+    tracker = HandTracker(model_from_state_dict(arch.make_synthetic_state(5)), HandTrackerOpts())
+    cams = _rig_cameras(rng)
+    frames, crops = [], []
+    for _ in range(3):
+        frame = rng.integers(0, 256, size=(synthetic.SRC_H, synthetic.SRC_W * 4)).astype(np.uint8)
+        mv = frame.reshape(synthetic.SRC_H, 4, -1)
+        frames.append(InputFrame(views=[ViewData(image=mv[:, v, :], camera=cams[v], camera_angle=0.0) for v in range(4)]))
+        gt = {}
+        for h in (0, 1):
+            W = np.eye(4, dtype=np.float32)
+            W[:3, :3] = synthetic.random_rotations(rng, 1)[0]
+            W[:3, 3] = (rng.uniform(-60, 60), rng.uniform(-40, 40), rng.uniform(380, 480))
+            gt[h] = SingleHandPose(joint_angles=np.zeros(22, np.float32), wrist_xform=W, hand_confidence=1.0)
+        crops.append(tracker.gen_crop_cameras(cams, [0.0] * 4, hm, gt, min_num_crops=1))
+    tracker.track_frame(frames[0], hm, crops[0])               # warm-up
+    torch.cuda.synchronize()
+    count = {"n": 0}
+    real_stream_sync, real_sync = torch.cuda.Stream.synchronize, torch.cuda.synchronize
+
+    def stream_sync(self):
+        count["n"] += 1
+        return real_stream_sync(self)
+
+    def dev_sync(*a, **k):
+        count["n"] += 1
+        return real_sync(*a, **k)
+
+    monkeypatch.setattr(torch.cuda.Stream, "synchronize", stream_sync)
+    monkeypatch.setattr(torch.cuda, "synchronize", dev_sync)
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        results = [tracker.track_frame(frames[i], hm, crops[i]) for i in (1, 2)]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+        monkeypatch.undo()
+    assert count["n"] == 2, count                              # one per frame
+    for res in results:
+        assert set(res.hand_poses) == {0, 1}
+        for h, pose in res.hand_poses.items():
+            assert isinstance(pose, SingleHandPose) and pose.landmarks_mm is not None
+            fast = landmarks_from_hand_pose(hm, pose, h)
+            assert fast is pose.landmarks_mm
+            slow = landmarks_from_hand_pose(hm, SingleHandPose(*pose), h)      # plain tuple: the FK round trip
+            assert np.abs(fast - slow).max() < 1e-3 and np.isfinite(fast).all()
+            other = landmarks_from_hand_pose(load_generic_hand_model(), pose, h)   # another model object: no cache hit
+            assert other is not pose.landmarks_mm
+
+
 def test_scale_calibration_head_through_tracker(hand_model_np):
     from umetrack_amd.lib.common.hand import load_generic_hand_model
     from umetrack_amd.lib.models.model_loader import model_from_state_dict

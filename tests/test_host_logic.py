@@ -155,9 +155,14 @@ if rank == 0:
     assert abs(fin.mpjpe - full["mpjpe"]) < 1e-9 and abs(fin.mpjpa - full["mpjpa"]) < 1e-9, (fin, full)
     assert fin.n_valid == full["n_valid"] and abs(fin.auc - full["auc"]) < 1e-9
     assert udist.max_over_ranks(float(rank)) == world - 1
-    sys.stdout.write(f"OK {world}\n")  # one write per rank: two ranks share the pipe
 else:
     udist.max_over_ranks(float(rank))
+# what a multi-GPU bench line says about its collective layer (every rank takes part)
+assert udist.min_max_over_ranks(10.0 + rank) == (10.0, 10.0 + world - 1)
+d = udist.describe(None, reps=5)
+assert d["backend"] == "gloo" and d["world"] == world and d["allreduce_us"] >= d["allreduce_us_min_rank"] > 0, d
+if rank == 0:
+    sys.stdout.write(f"OK {world}\n")  # one write per rank: two ranks share the pipe
 udist.barrier()
 '''
 
@@ -205,6 +210,11 @@ def test_stream_sharding_world_size_2_gloo(tmp_path):
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "STREAM OK 2" in out.stdout
+
+
+def test_collective_description_single_process():
+    assert udist.describe() == {"backend": None, "world": 1, "allreduce_us": None}
+    assert udist.min_max_over_ranks(3.5) == (3.5, 3.5)
 
 
 def test_hand_model_to_keeps_values_and_sets_kernel_dtypes():

@@ -2,7 +2,8 @@
 # copies what tools/round_profiles.sh left under gpurun_out/rp/ into profiles/ (run in the build container)
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
+export UMT_MEASURED_HEAD="$(git rev-parse --short HEAD)$(git diff --quiet HEAD -- umetrack_amd include || echo '+worktree')"
 cp $(find gpurun_out/rp/bench -name '*kernel_stats.csv' | head -1) profiles/${R}_bench_kernel_stats.csv
 for P in fp32 bf16 fp32x3; do
   python3 tools/layer_table.py gpurun_out/rp/lt_$P/t_kernel_trace.csv 4096 > profiles/${R}_layer_table_$P.txt
@@ -17,6 +18,7 @@ p='profiles/${R}_backbone_traffic.json'
 import os
 old=json.load(open(p)) if os.path.exists(p) else {"note": "HBM bytes per crop of the backbone launches (stem + convolutions) from rocprofv3 --pmc passes over tools/profile_forward.py at 16384 crops per forward call (the bench's call size): FETCH_SIZE (x2: gfx950 reports half the bytes of 16-byte-per-lane streaming reads) and WRITE_SIZE, KiB units; tools/round_profiles.sh, tools/traffic_json.py"}
 old['fp32']=dict(f, algorithmic_bytes_per_crop=8396928); old['bf16']=dict(b, algorithmic_bytes_per_crop=4222080); old['fp32x3']=dict(x, algorithmic_bytes_per_crop=8396928)
+old['measured_at_head']=os.environ.get('UMT_MEASURED_HEAD','unknown')  # git HEAD of the tree the PMC passes ran on (+worktree: uncommitted kernel changes on top)
 json.dump(old,open(p,'w'),indent=1)
 for q in ('fp32','bf16','fp32x3'):
     d=json.load(open('profiles/${R}_bench_line_%s.json'%q)); r=d['roofline']

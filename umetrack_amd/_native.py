@@ -17,13 +17,18 @@ HEAD_KNOWN_SKELETON, HEAD_PREDICT_SCALE = 0, 1
 WARP_CV2_FIXED_POINT, WARP_FLOAT, WARP_CV2_FIXED_POINT_F64 = 0, 1, 2
 WARP_NO_DEPTH_CHECK = 0x100
 METRIC_WORDS = 108
-ABI_VERSION = 2          # UMT_ABI_VERSION of include/umetrack_hip.h these signatures were written for
+ABI_VERSION = 3          # UMT_ABI_VERSION of include/umetrack_hip.h these signatures were written for
 STATUS_BITS = {1: "use_memory on a memory row whose previous extrinsics are singular (torch.inverse raises in the "
                   "reference, temporal.py:66); the sample ran as use_memory=False",
                2: "memory_idx outside the reserved memory rows",
                4: "sample_range row outside [0, n] or not 1 or 2 views",
                8: "a regressor output row was not finite (NaN/inf in the crop, the weights or the state)",
                16: "a landmark bone index outside [0, 16]"}
+
+STATUS_NONFINITE_OUTPUT = 8
+# the conditions under which the reference itself raises (torch.inverse on a singular matrix, index errors); a
+# non-finite regressor row is returned as NaN there and the run goes on
+STATUS_RAISING = 1 | 2 | 4 | 16
 
 _ERR_NAMES = {1: "invalid argument", 2: "bad state", 3: "state_dict key", 4: "HIP runtime",
               5: "workspace", 6: "unsupported"}
@@ -44,6 +49,7 @@ SIGNATURES = {
     "umt_model_clear_memory": (c_int, [_P]),
     "umt_model_read_memory": (c_int, [_P, _P, _P, _P]),
     "umt_model_status": (c_int, [_P, POINTER(c_int32), c_int, _P]),
+    "umt_model_status_async": (c_int, [_P, _P, c_int, _P]),
     "umt_backbone_workspace_bytes": (c_int64, [c_int]),
     "umt_head_workspace_bytes": (c_int64, [c_int, c_int]),
     "umt_forward_workspace_bytes": (c_int64, [c_int, c_int]),

@@ -1210,6 +1210,15 @@ extern "C" int umt_model_status(umt_model* m, int32_t* status_host, int clear, v
   return 0;
 }
 
+extern "C" int umt_model_status_async(umt_model* m, int32_t* status_dev, int clear, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(status_dev, UMT_ERR_INVALID, "model_status_async: null output");
+  hipStream_t s = (hipStream_t)stream;
+  UMT_CHECK_HIP(hipMemcpyAsync(status_dev, m->status, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+  if (clear) UMT_CHECK_HIP(hipMemsetAsync(m->status, 0, sizeof(int32_t), s));
+  return 0;
+}
+
 extern "C" int umt_model_layer_timing_read(umt_model* m, int max_layers, char* names, double* flop, double* ms,
                                            int* launches, int* n_layers) {
   UMT_TRY(check_ready(m));

@@ -67,3 +67,38 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def min_max_over_ranks(value: float, device=None) -> Tuple[float, float]:
+    """(min, max) of a per-rank scalar, so that a multi-GPU line shows load imbalance, not only the slowest rank."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return value, value
+    t = torch.tensor([value, -value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(-t[1].item()), float(t[0].item())
+
+
+def describe(device=None, reps: int = 20) -> dict:
+    """What the collective layer of this run actually is: backend, rank count and the measured latency of the one
+    collective on the path (all-reduce of the 108-word float64 partial vector), mean of `reps` after a warm-up.
+    Every rank must call it (it runs collectives); single-process runs report world 1 and no timing."""
+    import time
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return {"backend": None, "world": 1, "allreduce_us": None}
+    t = torch.zeros(108, dtype=torch.float64, device=device if device is not None else "cpu")
+    on_gpu = t.is_cuda
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize(t.device)
+    dist.all_reduce(t)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(t)
+    sync()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    lo, hi = min_max_over_ranks(us, device)
+    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "allreduce_us": hi, "allreduce_us_min_rank": lo,
+            "allreduce_words": 108, "allreduce_reps": reps}

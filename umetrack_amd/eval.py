@@ -188,14 +188,20 @@ def aggregate_metrics(output_dir: str, files: Optional[Sequence[str]] = None, re
     ``reduce_over_ranks`` every rank passes its own ``files`` and all ranks get the global result."""
     if files is None:
         files = find_result_files(output_dir)
-    # a rank without files still takes part in the all-reduce, with zeros on the device the collective runs on
-    total = torch.zeros(108, dtype=torch.float64, device="cuda" if torch.cuda.is_available() else "cpu")
+    total = None
     for f in files:
         d = load_result(f)
         if d["valid_tracking"].shape[1] == 0:
             continue
-        total += mu.metric_partials(torch.from_numpy(d["gt_keypoints"]), torch.from_numpy(d["tracked_keypoints"]),
-                                    torch.from_numpy(d["valid_tracking"]))
+        part = mu.metric_partials(torch.from_numpy(d["gt_keypoints"]), torch.from_numpy(d["tracked_keypoints"]),
+                                  torch.from_numpy(d["valid_tracking"]))
+        total = part.clone() if total is None else total + part.to(total.device)    # lives where the partials live
+    if total is None:
+        # a rank without files still takes part in the all-reduce, with zeros on the device the collective runs on:
+        # the GPU for RCCL ("nccl"), the host for gloo
+        on_gpu = (reduce_over_ranks and torch.distributed.is_available() and torch.distributed.is_initialized()
+                  and torch.distributed.get_backend() == "nccl")
+        total = torch.zeros(108, dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     if reduce_over_ranks:
         udist.all_reduce_partials(total)
     if float(total[1]) == 0:

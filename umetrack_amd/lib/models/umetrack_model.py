@@ -6,6 +6,7 @@ and forwards ``regress_pose_use_skeleton`` / ``regress_pose_pred_skel_scale`` to
 only torch work here is allocating output and workspace tensors.
 """
 import ctypes
+import logging
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -15,6 +16,8 @@ import torch
 from ... import _native as nat
 from ... import arch
 from .regressor import RegressorOutput
+
+logger = logging.getLogger(__name__)
 
 _PRECISIONS = {"fp32": nat.PREC_FP32, "bf16": nat.PREC_BF16, "fp32x3": nat.PREC_FP32_BF16X3}
 _PRECISIONS_INV = {v: k for k, v in _PRECISIONS.items()}
@@ -153,13 +156,26 @@ class UmeTrackModel:
                       "umt_model_status")
         return int(word.value)
 
-    def check_status(self) -> None:
+    def status_to(self, word: torch.Tensor, clear: bool = True) -> None:
+        """Enqueue a copy of the status word into `word` (int32[1] on the model's device) without waiting, so that a
+        caller's single device-to-host copy of its outputs carries it along."""
+        assert word.is_cuda and word.dtype == torch.int32 and word.numel() == 1
+        with torch.cuda.device(self._device):
+            nat.check(nat.lib().umt_model_status_async(self._h, nat.ptr(word), int(clear), nat.stream_ptr(self._device)),
+                      "umt_model_status_async")
+
+    def check_status(self, raise_nonfinite: bool = False) -> int:
         """Raise where the reference would have raised inside the forward pass (torch.inverse on a singular
-        matrix, an index out of range) or where the outputs are not finite.  Call it wherever results reach the
-        host anyway: it synchronises the stream."""
+        matrix, an index out of range).  A non-finite regressor output (UMT_STATUS_NONFINITE_OUTPUT) is what the
+        reference returns as NaN and carries on with: it is logged, and raised only on request.  Returns the bits.
+        Call it wherever results reach the host anyway: it synchronises the stream."""
         bits = self.status(clear=True)
-        if bits:
-            raise nat.UmtError("; ".join(msg for bit, msg in nat.STATUS_BITS.items() if bits & bit))
+        raising = bits if raise_nonfinite else bits & nat.STATUS_RAISING
+        if raising:
+            raise nat.UmtError("; ".join(msg for bit, msg in nat.STATUS_BITS.items() if raising & bit))
+        if bits & nat.STATUS_NONFINITE_OUTPUT:
+            logger.warning("a regressor output row was not finite (NaN pose returned, as the reference does)")
+        return bits
 
     def timing_enable(self, on: bool = True) -> None:
         nat.check(nat.lib().umt_model_timing_enable(self._h, int(on)))
@@ -187,7 +203,7 @@ class UmeTrackModel:
 
     # ---- forward ----
     def _forward(self, head: int, fd: InputFrameData, desc: InputFrameDesc, skel: Optional[InputSkeletonData],
-                 required_rows: Optional[int] = None) -> RegressorOutput:
+                 required_rows: Optional[int] = None, out: Optional[RegressorOutput] = None) -> RegressorOutput:
         if self._device is None:
             self.to(fd.left_images.device if fd.left_images.is_cuda else "cuda")
         dev, L = self._device, nat.lib()
@@ -215,11 +231,19 @@ class UmeTrackModel:
         # temporal.py:102: the memory grows to max(memory_idx)+1 rows (one host sync, as in the reference)
         if required_rows is None:
             required_rows = int(midx.max().item()) + 1
-        out = RegressorOutput(
-            joint_angles=torch.empty(bs, 22, dtype=f32, device=dev),
-            wrist_xfs=torch.empty(bs, 4, 4, dtype=f32, device=dev),
-            skel_scales=torch.empty(bs, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
-            landmark_uncertainty_sigmas=torch.empty(bs, 21, dtype=f32, device=dev))
+        if out is None:
+            out = RegressorOutput(
+                joint_angles=torch.empty(bs, 22, dtype=f32, device=dev),
+                wrist_xfs=torch.empty(bs, 4, 4, dtype=f32, device=dev),
+                skel_scales=torch.empty(bs, dtype=f32, device=dev) if head == nat.HEAD_PREDICT_SCALE else None,
+                landmark_uncertainty_sigmas=torch.empty(bs, 21, dtype=f32, device=dev))
+        else:       # caller-owned output buffers (e.g. slices of one block that goes to the host in one copy)
+            for t, shp in ((out.joint_angles, (bs, 22)), (out.wrist_xfs, (bs, 4, 4)), (out.landmark_uncertainty_sigmas, (bs, 21)),
+                           (out.skel_scales, (bs,))):
+                if t is None and shp == (bs,) and head != nat.HEAD_PREDICT_SCALE:
+                    continue
+                if t is None or tuple(t.shape) != shp or t.dtype != f32 or t.device != dev or not t.is_contiguous():
+                    raise ValueError(f"out: expected contiguous float32 {shp} on {dev}")
         nbytes = L.umt_forward_workspace_bytes(n, bs)
         ws = self._ws.get(dev, nbytes)
         with torch.cuda.device(dev):
@@ -233,17 +257,22 @@ class UmeTrackModel:
         return out
 
     def regress_pose_use_skeleton(self, frame_data: InputFrameData, frame_desc: InputFrameDesc,
-                                  skel_data: InputSkeletonData, required_rows: Optional[int] = None) -> RegressorOutput:
-        """umetrack_model.py:188-219."""
-        return self._forward(nat.HEAD_KNOWN_SKELETON, frame_data, frame_desc, skel_data, required_rows)
+                                  skel_data: InputSkeletonData, required_rows: Optional[int] = None,
+                                  out: Optional[RegressorOutput] = None) -> RegressorOutput:
+        """umetrack_model.py:188-219.  `required_rows` (= max(memory_idx) + 1, known to the caller) saves the
+        device read-back temporal.py:102 implies; `out` may hold caller-owned output buffers."""
+        return self._forward(nat.HEAD_KNOWN_SKELETON, frame_data, frame_desc, skel_data, required_rows, out)
 
     def regress_pose_pred_skel_scale(self, frame_data: InputFrameData, frame_desc: InputFrameDesc,
-                                     required_rows: Optional[int] = None) -> RegressorOutput:
-        """umetrack_model.py:221-242, including its assertion on single-view samples."""
-        sr = frame_desc.sample_range
-        assert bool(((sr[:, 1] - sr[:, 0]) != 1).all()), \
-            "Unsupported: found single-view samples when calibration scale"
-        return self._forward(nat.HEAD_PREDICT_SCALE, frame_data, frame_desc, None, required_rows)
+                                     required_rows: Optional[int] = None, out: Optional[RegressorOutput] = None,
+                                     views_checked: bool = False) -> RegressorOutput:
+        """umetrack_model.py:221-242, including its assertion on single-view samples (`views_checked`: the caller
+        has made that assertion on its host copy of sample_range, so no device value is read back here)."""
+        if not views_checked:
+            sr = frame_desc.sample_range
+            assert bool(((sr[:, 1] - sr[:, 0]) != 1).all()), \
+                "Unsupported: found single-view samples when calibration scale"
+        return self._forward(nat.HEAD_PREDICT_SCALE, frame_data, frame_desc, None, required_rows, out)
 
     # ---- stage-level calls (reference layouts), used by the parity tests ----
     def backbone(self, images: torch.Tensor) -> torch.Tensor:

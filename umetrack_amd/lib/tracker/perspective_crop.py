@@ -28,7 +28,14 @@ def skin_landmarks_np(hand_model: HandModel, joint_angles: np.ndarray, wrist_tra
 
 
 def landmarks_from_hand_pose(hand_model: HandModel, hand_pose: SingleHandPose, hand_idx: int) -> np.ndarray:
-    """World-space landmarks of a (left-model) hand pose; right hands mirror the wrist x axis."""
+    """World-space landmarks of a (left-model) hand pose; right hands mirror the wrist x axis
+    (perspective_crop.py:40-51).  A pose that HandTracker.track_frame returned already carries the landmarks the
+    GPU computed for it in the frame's launch chain; they are returned when `hand_model` is the model they were
+    skinned with (same object) and the pose has not been edited since."""
+    cached = getattr(hand_pose, "landmarks_mm", None)
+    if cached is not None and getattr(hand_pose, "landmarks_model", None) is hand_model \
+            and getattr(hand_pose, "landmarks_hand_idx", -1) == hand_idx:
+        return cached
     xf = np.array(hand_pose.wrist_xform, copy=True)
     if hand_idx == RIGHT_HAND_INDEX:
         xf[:, 0] *= -1

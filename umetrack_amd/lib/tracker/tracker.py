@@ -12,7 +12,9 @@ import numpy as np
 import torch
 
 from ..common import camera
-from ..common.hand import NUM_HANDS, HandModel, scaled_hand_model
+from ... import _native as nat
+from ..common.hand import NUM_HANDS, HandModel, hand_model_to, scaled_hand_model
+from ..common.hand_skinning import skin_landmarks
 from ..models.regressor import RegressorOutput
 from ..models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
 from . import warp as gpu_warp
@@ -51,15 +53,20 @@ class HandTrackerOpts:
     warp_mode: int = gpu_warp.MODE_CV2     # OpenCV-compatible fixed-point sampling (see csrc/warp.hip)
 
 
+def _check_view(vi, img):
+    if img.dtype != np.uint8 or img.ndim != 2:
+        raise ValueError(f"view {vi}: expected a 2-D uint8 image, got {img.dtype} {img.shape}")
+
+
 def _pack_views(views, pairs, device):
     """Upload the source views used by `pairs` [(src view index, crop camera)] once and build the
-    per-crop descriptors for umt_warp_crops."""
+    per-crop descriptors for umt_warp_crops (the single-image form; HandTracker stages whole frames through
+    _FrameIO instead)."""
     used = sorted({vi for vi, _ in pairs})
     chunks, start, pos = [], {}, 0
     for vi in used:
         img = np.ascontiguousarray(views[vi].image)
-        if img.dtype != np.uint8 or img.ndim != 2:
-            raise ValueError(f"view {vi}: expected a 2-D uint8 image, got {img.dtype} {img.shape}")
+        _check_view(vi, img)
         start[vi] = (pos, img.shape[1])
         chunks.append(img.reshape(-1))
         pos += img.size
@@ -68,12 +75,15 @@ def _pack_views(views, pairs, device):
     pitch = [start[vi][1] for vi, _ in pairs]
     src, dst = [], []
     for vi, crop_cam in pairs:
-        cam = views[vi].camera
-        if not isinstance(cam, camera.Fisheye62CameraModel):
-            raise TypeError("the GPU warp supports Fisheye62 source cameras (the raw_data rigs)")
-        src.append(gpu_warp.pack_fisheye(cam.width, cam.height, cam.f, cam.c, list(cam.distort), cam.camera_to_world_xf))
+        src.append(_pack_src(views[vi].camera))
         dst.append(gpu_warp.pack_pinhole(crop_cam.f, crop_cam.c, crop_cam.camera_to_world_xf))
     return flat, offs, pitch, np.stack(src), np.stack(dst)
+
+
+def _pack_src(cam) -> np.ndarray:
+    if not isinstance(cam, camera.Fisheye62CameraModel):
+        raise TypeError("the GPU warp supports Fisheye62 source cameras (the raw_data rigs)")
+    return gpu_warp.pack_fisheye(cam.width, cam.height, cam.f, cam.c, list(cam.distort), cam.camera_to_world_xf)
 
 
 def _warp_image(src_camera: camera.CameraModel, dst_camera: camera.CameraModel, src_image: np.ndarray,
@@ -89,6 +99,88 @@ def _warp_image(src_camera: camera.CameraModel, dst_camera: camera.CameraModel, 
     return torch.round(out[0] * 255.0).to(torch.uint8).cpu().numpy().astype(src_image.dtype)
 
 
+class TrackedHandPose(SingleHandPose):
+    """A SingleHandPose (same three fields, same tuple) that also carries the landmarks the tracker computed on the
+    GPU in the same launch chain as the pose: `landmarks_from_hand_pose` returns them when it is asked about the
+    hand model they were skinned with, instead of a second round trip to the device per hand."""
+    landmarks_mm: Optional[np.ndarray] = None
+    landmarks_model: Optional[HandModel] = None
+    landmarks_hand_idx: int = -1
+
+
+def _align(v: int, a: int = 256) -> int:
+    return (v + a - 1) // a * a
+
+
+class _FrameIO:
+    """Per-tracker staging: ONE pinned host block and its device twin.  Everything a frame sends to the GPU (source
+    pixels, camera rows, K, E, index tensors) is written into the pinned block and goes up in one asynchronous copy;
+    everything the frame returns (angles, wrist transforms, sigmas, scales, landmarks, the model's status word)
+    comes back in one copy.  The reference does the same traffic as ~10 separate pageable copies
+    (tracker.py:239-247, 156-161), each of which blocks the host."""
+
+    _IN = (("src", np.float64, gpu_warp.SRC_CAM_WORDS, "n"), ("dst", np.float64, gpu_warp.DST_CAM_WORDS, "n"),
+           ("off", np.int64, 1, "n"), ("sr", np.int64, 2, "bs"), ("midx", np.int64, 1, "bs"), ("hidx", np.int64, 1, "bs"),
+           ("K", np.float32, 9, "n"), ("E", np.float32, 16, "n"), ("pitch", np.int32, 1, "n"), ("use", np.uint8, 1, "bs"))
+    _OUT = (("status", np.int32, 4, "one"), ("angles", np.float32, 22, "bs"), ("wrist", np.float32, 16, "bs"),
+            ("sigmas", np.float32, 21, "bs"), ("scales", np.float32, 1, "bs"), ("lm", np.float32, 63, "bs"))
+    _TORCH = {np.float64: torch.float64, np.int64: torch.int64, np.float32: torch.float32, np.int32: torch.int32,
+              np.uint8: torch.uint8}
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.cap = (0, 0, 0)
+        self.pin = self.dev = None
+        self.layout = {}
+
+    def plan(self, n: int, bs: int, pixel_bytes: int):
+        """Section offsets for n crops, bs hands and `pixel_bytes` of source pixels: inputs, then the status words
+        (sent up as zeros, brought back with the outputs), then the outputs."""
+        key = (n, bs, _align(pixel_bytes))
+        if key == self.cap and self.pin is not None:
+            return self.layout
+        count = {"n": n, "bs": bs, "one": 1}
+        lay, pos = {}, 0
+        for name, dt, words, per in self._IN:
+            nb = np.dtype(dt).itemsize * words * count[per]
+            lay[name] = (pos, nb, dt, (count[per], words))
+            pos = _align(pos + nb)
+        lay["pixels"] = (pos, key[2], np.uint8, (key[2],))
+        pos = _align(pos + key[2])
+        lay["out_begin"] = pos
+        for name, dt, words, per in self._OUT:
+            nb = np.dtype(dt).itemsize * words * count[per]
+            lay[name] = (pos, nb, dt, (count[per], words))
+            if name == "status":
+                lay["in_end"] = pos + nb
+            pos = _align(pos + nb)
+        lay["out_end"] = pos
+        if self.pin is None or self.pin.numel() < pos:
+            self.pin = torch.zeros(pos + (pos >> 2), dtype=torch.uint8).pin_memory()
+            self.dev = torch.empty(self.pin.numel(), dtype=torch.uint8, device=self.device)
+            self._host = self.pin.numpy()
+        self.cap, self.layout = key, lay
+        return lay
+
+    def host(self, name) -> np.ndarray:
+        off, nb, dt, shape = self.layout[name]
+        return self._host[off:off + nb].view(dt).reshape(shape)
+
+    def devt(self, name) -> torch.Tensor:
+        off, nb, dt, shape = self.layout[name]
+        return self.dev[off:off + nb].view(self._TORCH[dt]).view(shape)
+
+    def upload(self):
+        end = self.layout["in_end"]
+        self.dev[:end].copy_(self.pin[:end], non_blocking=True)
+
+    def download(self):
+        """Enqueue the copy of the output sections and wait for it: the frame's ONE host synchronisation."""
+        a, b = self.layout["out_begin"], self.layout["out_end"]
+        self.pin[a:b].copy_(self.dev[a:b], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+
+
 class HandTracker:
     def __init__(self, model, opts: HandTrackerOpts) -> None:
         self._device = "cuda"
@@ -101,6 +193,11 @@ class HandTracker:
         self._min_required_vis_landmarks = opts.min_required_vis_landmarks
         self._warp_mode = opts.warp_mode
         self._valid_tracking_history = np.zeros(2, dtype=bool)
+        self._io = _FrameIO(getattr(model, "device", None) or "cuda")
+        self._hm_key: Optional[HandModel] = None     # the hand model whose device copies are cached below
+        self._hm_dev: Optional[HandModel] = None
+        self._skel: Optional[InputSkeletonData] = None
+        self._src_rows = {}                          # id(camera) -> (camera, packed row): rig cameras are constant
 
     def reset_history(self, clear_model_memory: bool = False) -> None:
         """tracker.py:98-99 clears the tracking history only (the next frame runs with use_memory=False, which
@@ -130,67 +227,137 @@ class HandTracker:
         if not crop_cameras:
             self.reset_history()
             return TrackingResult()
-        frame_data, frame_desc, skeleton = self._make_inputs(sample, hand_model, crop_cameras)
-        out = self._model.regress_pose_use_skeleton(frame_data, frame_desc, skeleton)
-        return self._gen_tracking_result(out, frame_desc.hand_idx.cpu().numpy(), crop_cameras)
+        frame_data, frame_desc, skeleton, hands = self._make_inputs(sample, hand_model, crop_cameras)
+        out = self._model.regress_pose_use_skeleton(frame_data, frame_desc, skeleton, required_rows=int(hands.max()) + 1,
+                                                    out=self._out_views(False))
+        return self._finish(out, hands, crop_cameras, hand_model)
 
     def track_frame_and_calibrate_scale(self, sample: InputFrame,
                                         crop_cameras: Dict[int, Dict[int, camera.PinholePlaneCameraModel]]) -> TrackingResult:
         if not crop_cameras:
             self.reset_history()
             return TrackingResult()
-        frame_data, frame_desc, _ = self._make_inputs(sample, None, crop_cameras)
-        out = self._model.regress_pose_pred_skel_scale(frame_data, frame_desc)
-        return self._gen_tracking_result(out, frame_desc.hand_idx.cpu().numpy(), crop_cameras)
+        frame_data, frame_desc, _, hands = self._make_inputs(sample, None, crop_cameras)
+        # umetrack_model.py:224-229; checked on the host copy of sample_range so that no device value is read back
+        assert bool((np.diff(self._io.host("sr"), axis=1) != 1).all()), \
+            "Unsupported: found single-view samples when calibration scale"
+        out = self._model.regress_pose_pred_skel_scale(frame_data, frame_desc, required_rows=int(hands.max()) + 1,
+                                                       out=self._out_views(True), views_checked=True)
+        return self._finish(out, hands, crop_cameras, None)
+
+    def _device_hand_model(self, hand_model_mm: HandModel):
+        """Skeleton (metres) and FK model (mm) of `hand_model_mm` on the GPU; constant per recording, so they are
+        uploaded when the caller's hand model changes, not once per frame (tracker.py:224-237 re-sends them)."""
+        if self._hm_key is not hand_model_mm:
+            hm = scaled_hand_model(hand_model_mm, MM_TO_M)
+            dev = self._io.device
+            self._skel = InputSkeletonData(joint_rotation_axes=hm.joint_rotation_axes.float().to(dev),
+                                           joint_rest_positions=hm.joint_rest_positions.float().to(dev))
+            self._hm_dev = hand_model_to(hand_model_mm, dev)
+            self._hm_key = hand_model_mm
+        return self._skel, self._hm_dev
+
+    def _src_row(self, cam) -> np.ndarray:
+        hit = self._src_rows.get(id(cam))
+        if hit is None or hit[0] is not cam:
+            if len(self._src_rows) > 64:
+                self._src_rows.clear()
+            hit = (cam, _pack_src(cam))
+            self._src_rows[id(cam)] = hit
+        return hit[1]
 
     def _make_inputs(self, sample: InputFrame, hand_model_mm: Optional[HandModel],
                      crop_cameras: Dict[int, Dict[int, camera.PinholePlaneCameraModel]]):
-        """tracker.py:194-247; all crops of the frame are warped in one kernel launch."""
-        pairs, ranges, hands, K, E = [], [], [], [], []
+        """tracker.py:194-247.  All crops of the frame are warped in one kernel launch; every input reaches the GPU
+        in one copy from a pinned block (_FrameIO)."""
+        pairs, ranges, hands = [], [], []
         for hand_idx, per_hand in crop_cameras.items():
             first = len(pairs)
             for cam_idx, crop_cam in per_hand.items():
                 pairs.append((cam_idx, crop_cam))
-                K.append(crop_cam.uv_to_window_matrix())
-                w2e = np.linalg.inv(crop_cam.camera_to_world_xf)
-                w2e[:3, 3] *= MM_TO_M
-                E.append(w2e)
             if len(pairs) > first:
                 hands.append(hand_idx)
                 ranges.append((first, len(pairs)))
         hands = np.asarray(hands)
-        flat, offs, pitch, src, dst = _pack_views(sample.views, pairs, self._device)
-        crops = gpu_warp.warp_crops(flat, offs, pitch, src, dst, tuple(int(v) for v in self._input_size),
-                                    self._warp_mode)
-        dev = self._device
-        frame_data = InputFrameData(left_images=crops,
-                                    intrinsics=torch.from_numpy(np.stack(K)).float().to(dev),
-                                    extrinsics_xf=torch.from_numpy(np.stack(E)).float().to(dev))
-        use_mem = self._valid_tracking_history[hands]      # enable_memory is stored but unused, as in the reference
-        frame_desc = InputFrameDesc(sample_range=torch.from_numpy(np.asarray(ranges)).long().to(dev),
-                                    memory_idx=torch.from_numpy(hands).long().to(dev),
-                                    use_memory=torch.from_numpy(use_mem).bool().to(dev),
-                                    hand_idx=torch.from_numpy(hands).long().to(dev))
+        n, bs = len(pairs), len(hands)
+        used = sorted({vi for vi, _ in pairs})
+        start, pos = {}, 0
+        for vi in used:
+            img = sample.views[vi].image
+            _check_view(vi, img)
+            start[vi] = (pos, img.shape)
+            pos += _align(img.size, 16)
+        io = self._io
+        io.plan(n, bs, pos)
+        px = io.host("pixels")
+        for vi in used:
+            p0, shp = start[vi]
+            np.copyto(px[p0:p0 + shp[0] * shp[1]].reshape(shp), sample.views[vi].image)
+        src, dst, off, pit, K, E = (io.host(k) for k in ("src", "dst", "off", "pitch", "K", "E"))
+        for k, (vi, crop_cam) in enumerate(pairs):
+            src[k] = self._src_row(sample.views[vi].camera)
+            dst[k] = gpu_warp.pack_pinhole(crop_cam.f, crop_cam.c, crop_cam.camera_to_world_xf)
+            off[k, 0] = start[vi][0]
+            pit[k, 0] = start[vi][1][1]
+            K[k] = crop_cam.uv_to_window_matrix().reshape(-1)
+            w2e = np.linalg.inv(crop_cam.camera_to_world_xf)
+            w2e[:3, 3] *= MM_TO_M
+            E[k] = w2e.reshape(-1)
+        io.host("sr")[:] = np.asarray(ranges)
+        io.host("midx")[:, 0] = hands
+        io.host("hidx")[:, 0] = hands
+        io.host("use")[:, 0] = self._valid_tracking_history[hands]   # enable_memory is stored but unused, as in the reference
+        io.host("status")[:] = 0
+        io.upload()
+        crops = gpu_warp.warp_crops(io.devt("pixels"), io.devt("off"), io.devt("pitch"), io.devt("src"), io.devt("dst"),
+                                    tuple(int(v) for v in self._input_size), self._warp_mode)
+        frame_data = InputFrameData(left_images=crops, intrinsics=io.devt("K").view(n, 3, 3),
+                                    extrinsics_xf=io.devt("E").view(n, 4, 4))
+        frame_desc = InputFrameDesc(sample_range=io.devt("sr"), memory_idx=io.devt("midx").view(bs),
+                                    use_memory=io.devt("use").view(bs).view(torch.bool), hand_idx=io.devt("hidx").view(bs))
         skeleton = None
         if hand_model_mm is not None:
-            hm = scaled_hand_model(hand_model_mm, MM_TO_M)
-            skeleton = InputSkeletonData(joint_rotation_axes=hm.joint_rotation_axes.float().to(dev),
-                                         joint_rest_positions=hm.joint_rest_positions.float().to(dev))
-        return frame_data, frame_desc, skeleton
+            skeleton, _ = self._device_hand_model(hand_model_mm)
+        return frame_data, frame_desc, skeleton, hands
 
-    def _gen_tracking_result(self, out: RegressorOutput, hand_indices: np.ndarray,
-                             crop_cameras: Dict[int, Dict[int, camera.PinholePlaneCameraModel]]) -> TrackingResult:
-        """tracker.py:249-291: metres -> millimetres, per-hand dicts, tracking history update."""
-        angles = out.joint_angles.cpu().numpy()
-        wrists = out.wrist_xfs.cpu().numpy()
-        check = getattr(self._model, "check_status", None)
-        if check is not None:               # the reference raises inside the forward pass; here after the copy-out
-            check()
+    def _out_views(self, with_scales: bool) -> RegressorOutput:
+        io = self._io
+        bs = io.cap[1]
+        return RegressorOutput(joint_angles=io.devt("angles"), wrist_xfs=io.devt("wrist").view(bs, 4, 4),
+                               skel_scales=io.devt("scales").view(bs) if with_scales else None,
+                               landmark_uncertainty_sigmas=io.devt("sigmas"))
+
+    def _finish(self, out: RegressorOutput, hands: np.ndarray,
+                crop_cameras: Dict[int, Dict[int, camera.PinholePlaneCameraModel]],
+                hand_model_mm: Optional[HandModel]) -> TrackingResult:
+        """tracker.py:156-161, 249-291: outputs to the host (one copy, with the landmarks and the model's status
+        word in it), metres -> millimetres, per-hand dicts, tracking history update."""
+        io = self._io
+        bs = len(hands)
+        status_dev = io.devt("status").view(-1)
+        if hand_model_mm is not None:       # the landmarks the eval loop asks for next (perspective_crop.py:40-51)
+            _, hm_dev = self._device_hand_model(hand_model_mm)
+            skin_landmarks(hm_dev, out.joint_angles, out.wrist_xfs, hand_idx=io.devt("hidx").view(bs), mirror_right=True,
+                           wrist_translation_scale=M_TO_MM, out=io.devt("lm").view(bs, 21, 3), status=status_dev[1:2])
+        self._model.status_to(status_dev[0:1])
+        io.download()
+        bits = int(io.host("status")[0, 0]) | int(io.host("status")[0, 1])
+        raising = bits & ~nat.STATUS_NONFINITE_OUTPUT
+        if raising:                         # where the reference raises inside the forward pass
+            raise nat.UmtError("; ".join(msg for bit, msg in nat.STATUS_BITS.items() if raising & bit))
+        if bits & nat.STATUS_NONFINITE_OUTPUT:      # the reference returns the NaN pose and goes on
+            logger.warning("non-finite regressor output in this frame (NaN pose returned)")
+        angles = io.host("angles").copy()
+        wrists = io.host("wrist").reshape(bs, 4, 4).copy()
         wrists[..., :3, 3] *= M_TO_MM
-        scales = None if out.skel_scales is None else out.skel_scales.cpu().numpy()
+        scales = io.host("scales").reshape(bs).copy() if out.skel_scales is not None else None
+        lms = io.host("lm").reshape(bs, 21, 3).copy() if hand_model_mm is not None else None
         poses, views, pred_scales = {}, {}, {}
-        for row, hand_idx in enumerate(hand_indices):
-            poses[hand_idx] = SingleHandPose(joint_angles=angles[row], wrist_xform=wrists[row], hand_confidence=1.0)
+        for row, hand_idx in enumerate(hands):
+            pose = TrackedHandPose(joint_angles=angles[row], wrist_xform=wrists[row], hand_confidence=1.0)
+            if lms is not None:
+                pose.landmarks_mm, pose.landmarks_model, pose.landmarks_hand_idx = lms[row], hand_model_mm, int(hand_idx)
+            poses[hand_idx] = pose
             views[hand_idx] = len(crop_cameras[hand_idx])
             if scales is not None:
                 pred_scales[hand_idx] = scales[row]
