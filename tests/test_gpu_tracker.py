@@ -93,8 +93,8 @@ def test_tracker_frames_match_oracle(hand_model_np):
 
 def test_track_frame_one_host_sync_and_cached_landmarks(monkeypatch):
     """a frame costs ONE host synchronisation.  After a warm-up frame (allocations, memory rows)
-    track_frame runs with torch's sync debug mode set to "error" - any pageable copy, .item() or .cpu() raises -
-    and the explicit stream synchronisations are counted.  The landmarks the result carries equal those of the
+    track_frame runs with torch's sync debug mode set to "warn" - every pageable copy, .item(), .cpu() and explicit
+    synchronisation warns - and both the warnings and the explicit synchronisations are counted.  The landmarks the result carries equal those of the
     generic landmarks_from_hand_pose round trip."""
     from umetrack_amd.lib.common.hand import load_generic_hand_model
     from umetrack_amd.lib.models.model_loader import model_from_state_dict
@@ -132,12 +132,17 @@ def test_track_frame_one_host_sync_and_cached_landmarks(monkeypatch):
 
     monkeypatch.setattr(torch.cuda.Stream, "synchronize", stream_sync)
     monkeypatch.setattr(torch.cuda, "synchronize", dev_sync)
-    torch.cuda.set_sync_debug_mode("error")
+    import warnings
+    torch.cuda.set_sync_debug_mode("warn")       # every synchronising torch call warns: implicit ones and the explicit one
     try:
-        results = [tracker.track_frame(frames[i], hm, crops[i]) for i in (1, 2)]
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            results = [tracker.track_frame(frames[i], hm, crops[i]) for i in (1, 2)]
     finally:
         torch.cuda.set_sync_debug_mode("default")
         monkeypatch.undo()
+    sync_warnings = [w for w in caught if "synchronizing" in str(w.message)]
+    assert len(sync_warnings) == 2, [str(w.message) for w in caught]      # pageable copies, .item(), .cpu() would add to it
     assert count["n"] == 2, count                              # one per frame
     for res in results:
         assert set(res.hand_poses) == {0, 1}

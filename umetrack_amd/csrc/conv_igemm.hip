@@ -725,7 +725,14 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   a.mg_w = (unsigned)(((uint64_t)1 << 32) / (uint64_t)w) + 1u;
   const bool force_gather = (L.flags & CONV_GATHER) != 0;
   if (L.taps == 9 && L.stride == 1 && w <= 48 && !force_gather) {
-    if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
+    // Few pixels (the tracker's per-frame call: 4 crops -> 144 pixels at 6x6): the wide tiles would leave 4-18
+    // workgroups on 256 CUs, each walking its whole K loop with 2-4 MFMAs per k-step.  One 32x32 tile per wave
+    // (128 pixels x 32 couts per workgroup) gives 4x the workgroups and a quarter of the K-loop latency; the k order
+    // per output is unchanged, so results are bit-identical to the wide configuration.
+    const int64_t wide_wgs = ((M + 127) / 128) * (L.cout_w % 128 == 0 ? L.cout_w / 128 : 1);
+    const bool few = wide_wgs < 64 && (L.cout_w % 128 == 0 || L.cout_w == 64);
+    if (few) launch_halo<4, 1, 1, 1>(a, stream);
+    else if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
     else if (L.cout_w == 96) launch_halo<UMT_CFG96>(a, stream);
     else if (L.cout_w == 64) launch_halo<UMT_CFG64>(a, stream);
     else if (L.cout_w == 32) launch_halo<UMT_CFG32>(a, stream);

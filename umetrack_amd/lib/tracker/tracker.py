@@ -114,7 +114,8 @@ def _align(v: int, a: int = 256) -> int:
 
 class _FrameIO:
     """Per-tracker staging: ONE pinned host block and its device twin.  Everything a frame sends to the GPU (source
-    pixels, camera rows, K, E, index tensors) is written into the pinned block and goes up in one asynchronous copy;
+    pixels, camera rows, K, E, index tensors) is written into the pinned block and goes up in two asynchronous copies
+    (the pixels as soon as they are staged, the small rows behind them);
     everything the frame returns (angles, wrist transforms, sigmas, scales, landmarks, the model's status word)
     comes back in one copy.  The reference does the same traffic as ~10 separate pageable copies
     (tracker.py:239-247, 156-161), each of which blocks the host."""
@@ -134,19 +135,18 @@ class _FrameIO:
         self.layout = {}
 
     def plan(self, n: int, bs: int, pixel_bytes: int):
-        """Section offsets for n crops, bs hands and `pixel_bytes` of source pixels: inputs, then the status words
-        (sent up as zeros, brought back with the outputs), then the outputs."""
-        key = (n, bs, _align(pixel_bytes))
+        """Section offsets for n crops, bs hands and `pixel_bytes` of source pixels: pixels, camera rows and index
+        tensors, then the status words (sent up as zeros, brought back with the outputs), then the outputs."""
+        key = (n, bs, max(_align(pixel_bytes), self.cap[2]))     # the pixel span only grows: no re-plan when fewer views are used
         if key == self.cap and self.pin is not None:
             return self.layout
         count = {"n": n, "bs": bs, "one": 1}
-        lay, pos = {}, 0
+        lay = {"pixels": (0, key[2], np.uint8, (key[2],))}
+        pos = params_begin = _align(key[2])
         for name, dt, words, per in self._IN:
             nb = np.dtype(dt).itemsize * words * count[per]
             lay[name] = (pos, nb, dt, (count[per], words))
             pos = _align(pos + nb)
-        lay["pixels"] = (pos, key[2], np.uint8, (key[2],))
-        pos = _align(pos + key[2])
         lay["out_begin"] = pos
         for name, dt, words, per in self._OUT:
             nb = np.dtype(dt).itemsize * words * count[per]
@@ -160,24 +160,34 @@ class _FrameIO:
             self.dev = torch.empty(self.pin.numel(), dtype=torch.uint8, device=self.device)
             self._host = self.pin.numpy()
         self.cap, self.layout = key, lay
+        # typed views of every section, host and device side, made once per layout (a frame touches ~20 of them)
+        self._hv, self._dv = {}, {}
+        for name, v in lay.items():
+            if isinstance(v, tuple):
+                off, nb, dt, shape = v
+                self._hv[name] = self._host[off:off + nb].view(dt).reshape(shape)
+                self._dv[name] = self.dev[off:off + nb].view(self._TORCH[dt]).view(shape)
+        self._spans = {"pixels": (self.pin[:key[2]], self.dev[:key[2]]),
+                       "params": (self.pin[params_begin:lay["in_end"]], self.dev[params_begin:lay["in_end"]]),
+                       "out": (self.pin[lay["out_begin"]:pos], self.dev[lay["out_begin"]:pos])}
         return lay
 
     def host(self, name) -> np.ndarray:
-        off, nb, dt, shape = self.layout[name]
-        return self._host[off:off + nb].view(dt).reshape(shape)
+        return self._hv[name]
 
     def devt(self, name) -> torch.Tensor:
-        off, nb, dt, shape = self.layout[name]
-        return self.dev[off:off + nb].view(self._TORCH[dt]).view(shape)
+        return self._dv[name]
 
-    def upload(self):
-        end = self.layout["in_end"]
-        self.dev[:end].copy_(self.pin[:end], non_blocking=True)
+    def upload(self, span: str):
+        """Enqueue the host-to-device copy of one span: "pixels" first, so that it travels while the host still
+        packs the camera rows, then "params" (which ends with the zeroed status words)."""
+        pin, dev = self._spans[span]
+        dev.copy_(pin, non_blocking=True)
 
     def download(self):
         """Enqueue the copy of the output sections and wait for it: the frame's ONE host synchronisation."""
-        a, b = self.layout["out_begin"], self.layout["out_end"]
-        self.pin[a:b].copy_(self.dev[a:b], non_blocking=True)
+        pin, dev = self._spans["out"]
+        pin.copy_(dev, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
 
 
@@ -293,22 +303,28 @@ class HandTracker:
         for vi in used:
             p0, shp = start[vi]
             np.copyto(px[p0:p0 + shp[0] * shp[1]].reshape(shp), sample.views[vi].image)
+        io.upload("pixels")
         src, dst, off, pit, K, E = (io.host(k) for k in ("src", "dst", "off", "pitch", "K", "E"))
+        c2w = np.stack([crop_cam.camera_to_world_xf for _, crop_cam in pairs]).astype(np.float64, copy=False)
+        w2e = np.linalg.inv(c2w)                                 # tracker.py:213-215, all crops of the frame at once
+        w2e[:, :3, 3] *= MM_TO_M
+        E[:] = w2e.reshape(n, 16)
+        dst[:, 4:] = c2w.reshape(n, 16)
+        K[:] = 0
+        K[:, 8] = 1
         for k, (vi, crop_cam) in enumerate(pairs):
             src[k] = self._src_row(sample.views[vi].camera)
-            dst[k] = gpu_warp.pack_pinhole(crop_cam.f, crop_cam.c, crop_cam.camera_to_world_xf)
+            fx, fy = np.broadcast_to(crop_cam.f, 2)
+            dst[k, 0], dst[k, 1], dst[k, 2], dst[k, 3] = fx, fy, crop_cam.c[0], crop_cam.c[1]
             off[k, 0] = start[vi][0]
             pit[k, 0] = start[vi][1][1]
-            K[k] = crop_cam.uv_to_window_matrix().reshape(-1)
-            w2e = np.linalg.inv(crop_cam.camera_to_world_xf)
-            w2e[:3, 3] *= MM_TO_M
-            E[k] = w2e.reshape(-1)
+            K[k, 0], K[k, 4], K[k, 2], K[k, 5] = fx, fy, crop_cam.c[0], crop_cam.c[1]      # uv_to_window_matrix, camera.py:323-327
         io.host("sr")[:] = np.asarray(ranges)
         io.host("midx")[:, 0] = hands
         io.host("hidx")[:, 0] = hands
         io.host("use")[:, 0] = self._valid_tracking_history[hands]   # enable_memory is stored but unused, as in the reference
         io.host("status")[:] = 0
-        io.upload()
+        io.upload("params")
         crops = gpu_warp.warp_crops(io.devt("pixels"), io.devt("off"), io.devt("pitch"), io.devt("src"), io.devt("dst"),
                                     tuple(int(v) for v in self._input_size), self._warp_mode)
         frame_data = InputFrameData(left_images=crops, intrinsics=io.devt("K").view(n, 3, 3),
