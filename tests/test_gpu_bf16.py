@@ -101,17 +101,21 @@ def test_bf16_end_to_end_cost_on_golden_sequence(models, golden_sequence):
     gm.reset_memory()
 
 
-def test_bf16_persistent_thin_kernel_bit_identical_to_halo_kernel(models, tmp_path):
-    """Stages 1-3 run on the persistent kernels of conv_thin.hip (stage 1: each BasicBlock fused into one launch with
-    the intermediate rows in LDS; 64 channels: weights in LDS; 128: weights streamed); with UMT_CONV_NOTHIN=1 (read once per process, hence the child process) they run
-    on conv3x3s1_halo_bf16.  Same arithmetic order, so the backbone features must agree bit for bit: for 7 crops
-    (fewer tiles than workgroups, ragged last tiles) and for 131 crops (several tiles per wave group, ragged)."""
+@pytest.mark.parametrize("switch", ["UMT_CONV_NOTHIN", "UMT_CONV_NODEPTH"])
+def test_bf16_persistent_kernels_bit_identical_to_per_layer_kernels(models, tmp_path, switch):
+    """By default stage 1 and the 32 -> 64 stride-2 layer run depth-first in ONE launch (stage1_depth.hip: role waves and
+    LDS rings), stages 2-3 on the persistent kernels of conv_thin.hip.  UMT_CONV_NODEPTH=1 (read once per process, hence
+    the child process) runs stage 1 as two fused BasicBlock launches + the fused stride-2 launch instead;
+    UMT_CONV_NOTHIN=1 runs every layer on conv3x3s1_halo_bf16 / conv3x3s2_ds_bf16.  Same arithmetic order everywhere, so
+    the backbone features must agree bit for bit: for 1 and 7 crops (one crop per workgroup, pipeline fill and drain
+    only), for 131 crops and for 300 (more crops than workgroups: crops streamed back to back through the rings)."""
     import os
     import subprocess
     import sys
     gm, _ = models
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = tmp_path / "halo.npy"
+    out = tmp_path / "ref.npy"
+    sizes = (1, 7, 131, 300)
     child = (
         "import sys, numpy as np, torch\n"
         f"sys.path.insert(0, {root!r})\n"
@@ -119,14 +123,16 @@ def test_bf16_persistent_thin_kernel_bit_identical_to_halo_kernel(models, tmp_pa
         "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
         f"gm = model_from_state_dict(arch.make_synthetic_state({int(gm_seed(models))})).to('cuda')\n"
         "gm.precision = 'bf16'\n"
-        "img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(31))\n"
-        f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:7].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()]))\n")
-    env = dict(os.environ, UMT_CONV_NOTHIN="1")
+        "img = torch.rand(300, 96, 96, generator=torch.Generator().manual_seed(31))\n"
+        f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in {sizes!r}]))\n")
+    env = dict(os.environ, **{switch: "1"})
     subprocess.run([sys.executable, "-c", child], check=True, env=env, timeout=110)
-    img = torch.rand(131, 96, 96, generator=torch.Generator().manual_seed(31))
+    img = torch.rand(300, 96, 96, generator=torch.Generator().manual_seed(31))
     gm.precision = "bf16"
     try:
-        got = np.concatenate([gm.backbone(img[:7].cuda()).cpu().numpy(), gm.backbone(img.cuda()).cpu().numpy()])
+        got = np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in sizes])
     finally:
         gm.precision = "fp32"
-    assert np.array_equal(got, np.load(out))
+    want = np.load(out)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, want), float(np.abs(got - want).max())

@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
-ks = [r for r in rows if "conv" in r["Kernel_Name"] or "stem" in r["Kernel_Name"] or "block32_fused" in r["Kernel_Name"]]
+ks = [r for r in rows if "conv" in r["Kernel_Name"] or "stem" in r["Kernel_Name"] or "block32_fused" in r["Kernel_Name"] or "stage1_depth" in r["Kernel_Name"]]
 ks.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(ks) if "stem" in r["Kernel_Name"]]
 seq = ks[idx[-1]:]
@@ -36,6 +36,12 @@ for r in seq:
         break
     name, fl = L[li]
     li += 1
+    if "stage1_depth" in r["Kernel_Name"]:       # both stage-1 blocks + the 32 -> 64 stride-2 layer + down-sample in one launch (bf16 mode)
+        for _ in range(4):
+            n2, f2 = L[li]
+            li += 1
+            fl += f2
+        name = "stage 1 + c1+ds 32->64 (depth-first)"
     if "block32_fused" in r["Kernel_Name"]:      # conv1 + conv2 of a stage-1 block in one launch (bf16 mode)
         n2, f2 = L[li]
         li += 1
@@ -45,5 +51,5 @@ for r in seq:
     kn = r["Kernel_Name"].replace("void umt::", "").split("(")[0]
     # rocprofv3's VGPR_Count is half the kernel's register allocation per lane (.amdhsa_next_free_vgpr, accumulators
     # included) on this toolchain; `regs` is the allocation that sets the waves per SIMD (512 / regs)
-    print(f"{name:26s} {kn:34s} {d:9.1f} us {fl * n / d / 1e6:7.1f} TF regs {2 * int(r['VGPR_Count']):>4d} lds {r['LDS_Block_Size']}")
+    print(f"{name:36s} {kn:34s} {d:9.1f} us {fl * n / d / 1e6:7.1f} TF regs {2 * int(r['VGPR_Count']):>4d} lds {r['LDS_Block_Size']}")
 print(f"total {tot / 1e3:.3f} ms -> {sum(f for _, f in L) * n / tot / 1e6:.1f} TFLOP/s")

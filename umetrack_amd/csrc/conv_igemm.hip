@@ -758,7 +758,8 @@ unsigned conv_flags_from_env() {
       {"UMT_CONV_NOTHIN", CONV_NO_THIN},         {"UMT_CONV_NOFUSE", CONV_NO_FUSE}, {"UMT_CONV_NOSTREAM128", CONV_NO_STREAM128},
       {"UMT_CONV_NOTHIN_F32", CONV_NO_THIN_F32}, {"UMT_CONV_GATHER", CONV_GATHER},  {"UMT_CONV_NOS2", CONV_NO_S2},
       {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}, {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}, {"UMT_CONV_NOS2P", CONV_NO_S2P},
-      {"UMT_CONV_NOPIPE32", CONV_NO_PIPE32},      {"UMT_CONV_NOPIPE64", CONV_NO_PIPE64}};
+      {"UMT_CONV_NOPIPE32", CONV_NO_PIPE32},      {"UMT_CONV_NOPIPE64", CONV_NO_PIPE64},
+      {"UMT_CONV_NODEPTH", CONV_NO_DEPTH}};
   unsigned f = 0;
   for (const auto& s : kSwitches)
     if (getenv(s.name)) f |= s.bit;
@@ -775,6 +776,7 @@ int conv_prepare_device() {
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, true>), lds));
   UMT_TRY(conv_x3_prepare_device());
   UMT_TRY(conv_chain_prepare_device());
+  UMT_TRY(stage1_depth_prepare_device());
   return conv_thin_prepare_device();
 }
 

@@ -564,6 +564,25 @@ static int run_blocks_bf16(umt_model* m, size_t b0, size_t b1, int n, uint16_t*&
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
     const uint16_t* res = x;
+    if (i == 0 && b1 >= 3 && !B.has_down && !m->blocks[1].has_down && m->blocks[2].has_down &&
+        stage1_depth_applicable(B.conv1, B.conv2, m->blocks[1].conv1, m->blocks[1].conv2, m->blocks[2].conv1, &m->blocks[2].down, hw, hw)) {
+      // both stage-1 blocks, conv1 of stage 2's first block and its down-sample branch depth-first in one launch
+      const BlockLayers &B1 = m->blocks[1], &B2 = m->blocks[2];
+      UMT_TRY(launch_stage1_depth_bf16(B.conv1, B.conv2, B1.conv1, B1.conv2, B2.conv1, B2.down, x, n, t, d, s));
+      if (m->layer_timing) {
+        const double px = (double)n * hw * hw;
+        UMT_TRY(layer_mark(m, s, "stage1 depth 2xblock32+s2+ds hw48",
+                           2.0 * px * (4.0 * 9 * 32 * 32 + (9.0 * 32 * 64 + 32.0 * 64) / 4.0)));
+      }
+      const int hw2 = hw / 2;
+      UMT_TRY(launch_conv_bf16(B2.conv2, t, n, hw2, hw2, d, y, 0, s));
+      UMT_TRY(conv_mark(m, s, "c2+res", B2.conv2, nullptr, n, hw2));
+      uint16_t* old = x;
+      x = y;
+      y = old;
+      i = 2;
+      continue;
+    }
     if (!B.has_down && block32_fused_applicable(B.conv1, B.conv2, hw, hw)) {     // conv1 -> conv2 (+x) with t kept on chip
       UMT_TRY(launch_block32_fused_bf16(B.conv1, B.conv2, x, n, y, s));
       if (m->layer_timing) {

@@ -63,6 +63,7 @@ enum : unsigned {
   CONV_NO_PIPE64 = 2048u,   // UMT_CONV_NOPIPE64: bf16 64 -> 64 layers on the two-group conv3x3_wlds64_bf16 instead of conv3x3_pipe64_bf16
   CONV_NO_PIPE32 = 1024u,   // UMT_CONV_NOPIPE32: fp32 stage 1 on the two-group conv3x3_wlds32_f32 instead of conv3x3_pipe32_f32
   CONV_NO_S2P = 512u,       // UMT_CONV_NOS2P: fp32 fused stride-2 layers on the one-tile-per-workgroup kernel instead of the persistent one
+  CONV_NO_DEPTH = 4096u,    // UMT_CONV_NODEPTH: bf16 stage 1 + the 32 -> 64 stride-2 layer as three launches instead of stage1_depth_bf16
   CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
 };
 unsigned conv_flags_from_env();
@@ -154,6 +155,15 @@ int launch_conv_thin_f32(const ConvLayer& L, const float* in, int n, int h, int 
 bool block32_fused_applicable(const ConvLayer& c1, const ConvLayer& c2, int h, int w);
 int launch_block32_fused_bf16(const ConvLayer& c1, const ConvLayer& c2, const uint16_t* in, int n, uint16_t* out,
                               hipStream_t stream);
+
+// stage1_depth.hip: both stage-1 BasicBlocks and the first stride-2 layer (+ its down-sample branch) of the bf16
+// backbone in one launch, intermediate tensors in LDS rings
+bool stage1_depth_applicable(const ConvLayer& c1a, const ConvLayer& c2a, const ConvLayer& c1b, const ConvLayer& c2b,
+                             const ConvLayer& s2, const ConvLayer* ds, int h, int w);
+int launch_stage1_depth_bf16(const ConvLayer& c1a, const ConvLayer& c2a, const ConvLayer& c1b, const ConvLayer& c2b,
+                             const ConvLayer& s2, const ConvLayer& ds, const uint16_t* in, int n, uint16_t* out_t,
+                             uint16_t* out_d, hipStream_t stream);
+int stage1_depth_prepare_device();
 
 // stem.hip: conv3x3(1->32)+bias+BN+ReLU+maxpool2 ; images (n,96,96) -> rows [n*48*48][32]
 struct StemParams {
