@@ -264,3 +264,35 @@ def test_bf16_one_role_64_channel_kernel_bit_identical_to_two_group_kernel(monke
     monkeypatch.setenv("UMT_CONV_NOPIPE64", "1")
     ref = run()
     assert torch.isfinite(got).all() and torch.equal(got, ref)
+
+
+@pytest.mark.gpu
+def test_fp32_few_pixel_kernel_bit_identical_to_halo_kernel(tmp_path):
+    """fp32 mode with few crops (the tracker's per-frame call is 4): the 64/128/256-channel stride-1 layers run on
+    conv_small.hip (16x16x4 matrix instructions, k-slots in the channel order of four 32x32x2 instructions); with
+    UMT_CONV_NOSMALL=1 (read once per process, hence the child process) on conv3x3s1_halo_f32<4,1,1,1>.  Same chain per
+    output, so the backbone features must agree bit for bit: 1, 4 and 13 crops (ragged 16-pixel tiles), and 40 crops,
+    where the 64-channel layers are past the switch-over and the 256-channel layers are not."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "halo.npy"
+    sizes = (1, 4, 13, 40)
+    body = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from umetrack_amd import arch\n"
+        "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
+        "gm = model_from_state_dict(arch.make_synthetic_state(3)).to('cuda')\n"
+        "img = torch.rand(40, 96, 96, generator=torch.Generator().manual_seed(77))\n"
+        f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in {sizes!r}]))\n")
+    subprocess.run([sys.executable, "-c", body], check=True, env=dict(os.environ, UMT_CONV_NOSMALL="1"), timeout=110)
+    from umetrack_amd import arch
+    gm = model_from_state_dict(arch.make_synthetic_state(3)).to("cuda")
+    img = torch.rand(40, 96, 96, generator=torch.Generator().manual_seed(77))
+    got = np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in sizes])
+    want = np.load(out)
+    assert np.isfinite(got).all() and np.array_equal(got, want), float(np.abs(got - want).max())

@@ -10,7 +10,8 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libumetrack_hip.so")
+# (UMT_LIB_PATH: diagnostics only - A/B runs of an experiment build of the same ABI, e.g. tools/bin/*.so)
+LIB_PATH = os.environ.get("UMT_LIB_PATH") or os.path.join(_HERE, "libumetrack_hip.so")
 
 PREC_FP32, PREC_BF16, PREC_FP32_BF16X3 = 0, 1, 2
 HEAD_KNOWN_SKELETON, HEAD_PREDICT_SCALE = 0, 1

@@ -699,6 +699,9 @@ static void launch_cfg(const ConvArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((conv_igemm_f32<WAVES_M, WAVES_N, TM, TN>), grid, dim3(256), 0, stream, a);
 }
 
+bool conv_small_applicable(const ConvArgs& a, bool force_off);      // conv_small.hip
+void launch_conv_small(const ConvArgs& a, hipStream_t stream);
+
 int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
                 float* out, hipStream_t stream) {
   UMT_REQUIRE(L.taps == 1 || L.taps == 9, UMT_ERR_INVALID, "conv: taps must be 1 or 9, got %d", L.taps);
@@ -726,12 +729,14 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
   const bool force_gather = (L.flags & CONV_GATHER) != 0;
   if (L.taps == 9 && L.stride == 1 && w <= 48 && !force_gather) {
     // Few pixels (the tracker's per-frame call: 4 crops -> 144 pixels at 6x6): the wide tiles would leave 4-18
-    // workgroups on 256 CUs, each walking its whole K loop with 2-4 MFMAs per k-step.  One 32x32 tile per wave
-    // (128 pixels x 32 couts per workgroup) gives 4x the workgroups and a quarter of the K-loop latency; the k order
-    // per output is unchanged, so results are bit-identical to the wide configuration.
+    // workgroups on 256 CUs, each walking its whole K loop with 2-4 MFMAs per k-step.  conv_small.hip runs these
+    // launches on 16x16x4 tiles (16 pixels x 16 couts per wave: a sixteenth of the K-loop latency of the wide
+    // configuration); with UMT_CONV_NOSMALL one 32x32 tile per wave.  The k order per output is the same in all
+    // three, so results are bit-identical.
     const int64_t wide_wgs = ((M + 127) / 128) * (L.cout_w % 128 == 0 ? L.cout_w / 128 : 1);
     const bool few = wide_wgs < 64 && (L.cout_w % 128 == 0 || L.cout_w == 64);
-    if (few) launch_halo<4, 1, 1, 1>(a, stream);
+    if (few && conv_small_applicable(a, (L.flags & CONV_NO_SMALL) != 0)) launch_conv_small(a, stream);   // 16x16x4 tiles (conv_small.hip)
+    else if (few) launch_halo<4, 1, 1, 1>(a, stream);
     else if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);
     else if (L.cout_w == 96) launch_halo<UMT_CFG96>(a, stream);
     else if (L.cout_w == 64) launch_halo<UMT_CFG64>(a, stream);
@@ -759,7 +764,7 @@ unsigned conv_flags_from_env() {
       {"UMT_CONV_NOTHIN_F32", CONV_NO_THIN_F32}, {"UMT_CONV_GATHER", CONV_GATHER},  {"UMT_CONV_NOS2", CONV_NO_S2},
       {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}, {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}, {"UMT_CONV_NOS2P", CONV_NO_S2P},
       {"UMT_CONV_NOPIPE32", CONV_NO_PIPE32},      {"UMT_CONV_NOPIPE64", CONV_NO_PIPE64},
-      {"UMT_CONV_NODEPTH", CONV_NO_DEPTH}};
+      {"UMT_CONV_NODEPTH", CONV_NO_DEPTH},        {"UMT_CONV_NOSMALL", CONV_NO_SMALL}};
   unsigned f = 0;
   for (const auto& s : kSwitches)
     if (getenv(s.name)) f |= s.bit;

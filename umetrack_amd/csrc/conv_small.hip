@@ -1,0 +1,164 @@
+// Stride-1 3x3 convolution for FEW pixels (the tracker's per-frame call: 4 crops -> 144 pixels at 6x6, 576 at 12x12;
+// lib/tracker/tracker.py:141-168 calls the model on one frame's crops).  conv3x3s1_halo_f32 gives such a launch 4-20
+// workgroups, and each wave walks its whole K loop on 32x32x2 matrix instructions: 64 cycles per 2 channels whatever
+// the tile holds, 25-46 us per layer on an otherwise idle chip.  Here the tile is 16 pixels x 16 output channels per
+// wave on v_mfma_f32_16x16x4_f32 (32 cycles per 4 channels): a quarter of the K-loop latency and 4x the workgroups.
+//
+// Arithmetic: the four k-slots of the 16x16x4 instruction take channels {0, 4, 1, 5} and then {2, 6, 3, 7} of every
+// 8-channel group, which is the order in which four 32x32x2 instructions (lane half h = k: channels 8g + e, 8g + 4 + e
+// for e = 0..3) add them; chunks of 32 channels outermost, then taps, then groups, as conv3x3s1_halo_f32; the same
+// epilogue expression.  Results are bit-identical to that kernel's (tests/test_gpu_edges.py), as head_seq.hip's use of
+// the same instruction is to the head's 32x32x2 kernels.
+#include "conv_f32_common.h"
+
+namespace umt {
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+
+constexpr int SM_BM = 16, SM_BN = 64;        // workgroup tile: 16 pixels x 64 output channels (4 waves x 16)
+
+template <bool RES>
+__global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sA[];   // (16 + 2W + 2) rows x LDA + one zero row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * SM_BM, n0 = blockIdx.y * SM_BN + wave * 16;
+  const int ks = lane >> 4, lc = lane & 15;                    // k-slot; pixel (B operand) / output channel (A operand) of this lane
+  const int W = a.W, H = a.H;
+  const int rows = SM_BM + 2 * W + 2;
+  const int g0 = m0 - W - 1;                                   // global pixel row of LDS row 0
+  const int c8_total = a.cin_s >> 3;
+  const int nchunks = (a.cin_s + KC - 1) / KC;
+  const int perm = (ks & 1) * 4 + (ks >> 1);                   // channel of this k-slot inside an 8-channel group: 0, 4, 1, 5 (then + 2)
+
+  // the lane's pixel and the LDS byte address of each of its 9 tap rows (the all-zero row where the neighbour does not exist)
+  int arow[9];
+  {
+    const int m = m0 + lc;
+    const bool live = m < a.M;
+    const int mm = live ? m : 0;
+    const int rem = mm - div_magic32(mm, H * W, a.mg_hw) * (H * W);
+    const int y = div_magic32(rem, W, a.mg_w), x = rem - y * W;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = y + ky - 1, xx = x + kx - 1;
+        const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        arow[ky * 3 + kx] = ((ok ? lc + ky * W + kx : rows) * LDA + perm) * 4;
+      }
+  }
+  if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + rows * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // weights: lane reads packed[tap][c8][h = ks & 1][n0 + lc][0..3] and uses elements (ks >> 1) and (ks >> 1) + 2, one tap
+  // ahead of the MFMAs.  (Measured and dropped: the whole next chunk in flight as 72 four-byte loads per lane - slower,
+  // 0.94 against 0.86 ms per frame: four waves x 16 output channels each pull the full weight stream through the CU's one
+  // texture path.  What these launches want next is 64 pixels x 16 output channels per workgroup with the weights
+  // staged once in LDS: an eighth of the traffic.)
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const int wvoff = (int)((((size_t)(ks & 1) * a.cout_w + n0 + lc) * 4) * sizeof(float));
+  const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float), w_tap = (size_t)c8_total * w_c8;
+  const bool hi = (ks >> 1) != 0;
+  float2 bcur[4], bnext[4];
+  auto load_b = [&](float2 (&dst)[4], int tap, int chunk) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int c8 = min(chunk * 4 + c, c8_total - 1);
+      const f32x4v v = __builtin_bit_cast(f32x4v, (u32x4v)__builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, (int)(tap * w_tap + c8 * w_c8), 0));
+      dst[c] = hi ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
+    }
+  };
+  load_b(bcur, 0, 0);
+
+  // epilogue constants of the lane's four output channels n0 + 4 ks + {0..3}
+  const int co = n0 + 4 * ks;
+  const int coc = min(co, a.cout_w - 4);
+  const float4 cb = *reinterpret_cast<const float4*>(a.bias + coc), cs = *reinterpret_cast<const float4*>(a.scale + coc),
+               ch = *reinterpret_cast<const float4*>(a.shift + coc);
+  const int mout = m0 + lc;
+  float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (RES && mout < a.M && co < a.cout_s) rr = *reinterpret_cast<const float4*>(a.residual + (size_t)mout * a.cout_s + co);
+
+  // A staging as conv3x3s1_halo_f32: slot idx = tid + 256 k (row idx >> 3, channel quad idx & 7), next chunk prefetched
+  constexpr int NLD = (SM_BM + 2 * 48 + 2) * 8 / 256 + 1;      // W <= 48
+  float4 areg[NLD];
+  unsigned aok = 0;
+  auto load_a = [&](int chunk) {
+    const int c0 = chunk * KC;
+    aok = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 3, q = idx & 7;
+      const int g = g0 + r;
+      const bool ok = r < rows && g >= 0 && g < a.M && (c0 + 4 * q) < a.cin_s;
+      const size_t off = ok ? (size_t)g * a.cin_s + c0 + 4 * q : 0;
+      areg[k] = *reinterpret_cast<const float4*>(a.in + off);
+      aok |= (ok ? 1u : 0u) << k;
+    }
+  };
+  load_a(0);
+
+  f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+  const char* sAb = reinterpret_cast<const char*>(sA);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      float4 v = areg[k];
+      if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap < 8) load_b(bnext, tap + 1, chunk);
+      else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
+      if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (chunk * 4 + c >= c8_total) continue;               // zero channel groups past the end (cin_s = 80): skipped, as the halo kernel's one-tile form
+        const float p1 = *reinterpret_cast<const float*>(sAb + arow[tap] + c * 32);
+        const float p2 = *reinterpret_cast<const float*>(sAb + arow[tap] + c * 32 + 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].x, p1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].y, p2, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
+    }
+    __syncthreads();
+  }
+
+  if (mout < a.M && co < a.cout_s) {
+    float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    v.x = (v.x + cb.x) * cs.x + ch.x;
+    v.y = (v.y + cb.y) * cs.y + ch.y;
+    v.z = (v.z + cb.z) * cs.z + ch.z;
+    v.w = (v.w + cb.w) * cs.w + ch.w;
+    if (RES) { v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+    if (a.relu) {
+      v.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.x), 0));
+      v.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.y), 0));
+      v.z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.z), 0));
+      v.w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.w), 0));
+    }
+    *reinterpret_cast<float4*>(a.out + (size_t)mout * a.cout_s + co) = v;
+  }
+}
+
+bool conv_small_applicable(const ConvArgs& a, bool force_off) {
+  return !force_off && a.taps == 9 && a.stride == 1 && a.W <= 48 && a.cout_w % SM_BN == 0 && a.cin_s % 8 == 0;
+}
+
+void launch_conv_small(const ConvArgs& a, hipStream_t stream) {
+  dim3 grid((a.M + SM_BM - 1) / SM_BM, a.cout_w / SM_BN);
+  const size_t lds = (size_t)(SM_BM + 2 * a.W + 2 + 1) * LDA * sizeof(float);
+  if (a.residual)
+    hipLaunchKernelGGL(conv3x3s1_small_f32<true>, grid, dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL(conv3x3s1_small_f32<false>, grid, dim3(256), lds, stream, a);
+}
+
+}  // namespace umt

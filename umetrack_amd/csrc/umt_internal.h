@@ -64,6 +64,7 @@ enum : unsigned {
   CONV_NO_PIPE32 = 1024u,   // UMT_CONV_NOPIPE32: fp32 stage 1 on the two-group conv3x3_wlds32_f32 instead of conv3x3_pipe32_f32
   CONV_NO_S2P = 512u,       // UMT_CONV_NOS2P: fp32 fused stride-2 layers on the one-tile-per-workgroup kernel instead of the persistent one
   CONV_NO_DEPTH = 4096u,    // UMT_CONV_NODEPTH: bf16 stage 1 + the 32 -> 64 stride-2 layer as three launches instead of stage1_depth_bf16
+  CONV_NO_SMALL = 8192u,    // UMT_CONV_NOSMALL: few-pixel fp32 launches on conv3x3s1_halo_f32<4,1,1,1> instead of conv_small.hip
   CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
 };
 unsigned conv_flags_from_env();

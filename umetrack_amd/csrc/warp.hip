@@ -105,7 +105,8 @@ __device__ inline void map_point(const SrcCam& s, const DstCam& d, int u, int v,
 // ---- interpolated map (UMT_WARP_CV2_FIXED_POINT, crops up to 96 wide whose camera shares the source camera's centre) ----
 // The map is smooth, so its float64 values on a grid of 8-pixel spacing (15 x 7 nodes around a band of 32 rows) determine it between
 // the nodes: bicubic Lagrange interpolation on the 4x4 nodes around a cell.  The interpolation error of every cell is
-// MEASURED, not assumed: the float64 map is also evaluated at the midpoints of the cell's four edges (where the error of the
+// MEASURED, not assumed: the float64 map is also evaluated at the midpoint of the central interval of EVERY 1-D stencil
+// line the band uses - all 7 node rows (84 points) and all 15 node columns (60 points) - (where the error of the
 // 1-D cubic along that edge peaks; the error of the tensor-product interpolant inside the cell is the sum of the two 1-D
 // errors to leading order), and a pixel's interpolated coordinate is accepted only when its distance to the nearest 1/32-px
 // rounding boundary exceeds twice (1.25 x largest horizontal-edge error + largest vertical-edge error over the stencil's grid
@@ -119,21 +120,23 @@ constexpr int INX = 96 / IG + 3;            // 15 node columns: u = IG * (nx - 1
 constexpr int INY = IBH / IG + 3;           // 7 node rows of a band: v = v0 + IG * (ny - 1)
 constexpr int ICX = 96 / IG, ICY = IBH / IG;   // 12 x 4 cells
 constexpr int I_NODES = INX * INY;          // 105
-constexpr int I_HE = (ICY + 1) * ICX;       // 60 horizontal-edge midpoints (row r = 0..4, cell column c)
-constexpr int I_VE = ICY * (ICX + 1);       // 52 vertical-edge midpoints (cell row, column c = 0..12)
-constexpr int I_EVALS = I_NODES + I_HE + I_VE;   // 217 float64 evaluations per band of 3072 pixels: one per thread
+constexpr int IHR = ICY + 3;                // 7 rows of horizontal-edge midpoints: EVERY node row of the band's grid
+constexpr int IVC = ICX + 3;                // 15 columns of vertical-edge midpoints: every node column
+constexpr int I_HE = IHR * ICX;             // 84 horizontal-edge midpoints (node row r = 0..6, between node columns c+1 and c+2)
+constexpr int I_VE = ICY * IVC;             // 60 vertical-edge midpoints (between node rows cj+1 and cj+2, node column c = 0..14)
+constexpr int I_EVALS = I_NODES + I_HE + I_VE;   // 249 float64 evaluations per band of 3072 pixels: one per thread
 static_assert(I_EVALS <= WARP_THREADS && IBH * 96 == WARP_BAND_PX, "one evaluation per thread, one band per workgroup");
-constexpr int I_OFF_DN = WARP_QCAP * 10;             // double2[217]  (the queue owns [0, 10 * QCAP): 2-byte ids, 8-byte results)
-constexpr int I_OFF_NF = I_OFF_DN + 16 * 218;        // float2[105] nodes relative to the band's centre node, 1/32 px
-constexpr int I_OFF_ERR = I_OFF_NF + 8 * 106;        // float[112] measured errors
-constexpr int I_OFF_CELL = I_OFF_ERR + 4 * 112;      // float[48] per-cell bound
+constexpr int I_OFF_DN = WARP_QCAP * 10;             // double2[249]  (the queue owns [0, 10 * QCAP): 2-byte ids, 8-byte results)
+constexpr int I_OFF_NF = I_OFF_DN + 16 * 250;        // float2[105] nodes relative to the band's centre node, 1/32 px
+constexpr int I_OFF_ERR = I_OFF_NF + 8 * 106;        // float[144] measured errors
+constexpr int I_OFF_CELL = I_OFF_ERR + 4 * 144;      // float[48] per-cell bound
 constexpr int I_OFF_WT = I_OFF_CELL + 4 * 48;        // float4[8] cubic weights of the 8 sub-positions
 static_assert(I_OFF_WT + 128 <= WARP_LDS_BYTES && I_OFF_WT % 16 == 0 && I_OFF_NF % 8 == 0, "interpolation tables");
 
 __device__ inline void interp_eval_pos(int e, int v0, int& u, int& v) {
   if (e < I_NODES) { const int ny = e / INX, nx = e - ny * INX; u = IG * (nx - 1); v = v0 + IG * (ny - 1); }
-  else if (e < I_NODES + I_HE) { const int i = e - I_NODES, r = i / ICX, c = i - r * ICX; u = IG * c + IG / 2; v = v0 + IG * r; }
-  else { const int i = e - I_NODES - I_HE, cj = i / (ICX + 1), c = i - cj * (ICX + 1); u = IG * c; v = v0 + IG * cj + IG / 2; }
+  else if (e < I_NODES + I_HE) { const int i = e - I_NODES, r = i / ICX, c = i - r * ICX; u = IG * c + IG / 2; v = v0 + IG * (r - 1); }
+  else { const int i = e - I_NODES - I_HE, cj = i / IVC, c = i - cj * IVC; u = IG * (c - 1); v = v0 + IG * cj + IG / 2; }
 }
 
 __device__ inline float nan_max(float a, float b) { return (a > b || a != a) ? a : b; }   // NaN if either is
@@ -273,12 +276,12 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
         double ix, iy;
         if (tid < I_HE) {
           const int r = tid / ICX, c = tid - r * ICX;
-          const double2* row = dn + (r + 1) * INX + c;
+          const double2* row = dn + r * INX + c;
           ix = (9.0 * (row[1].x + row[2].x) - (row[0].x + row[3].x)) * 0.0625;
           iy = (9.0 * (row[1].y + row[2].y) - (row[0].y + row[3].y)) * 0.0625;
         } else {
-          const int i = tid - I_HE, cj = i / (ICX + 1), c = i - cj * (ICX + 1);
-          const double2* col = dn + cj * INX + c + 1;
+          const int i = tid - I_HE, cj = i / IVC, c = i - cj * IVC;
+          const double2* col = dn + cj * INX + c;
           ix = (9.0 * (col[INX].x + col[2 * INX].x) - (col[0].x + col[3 * INX].x)) * 0.0625;
           iy = (9.0 * (col[INX].y + col[2 * INX].y) - (col[0].y + col[3 * INX].y)) * 0.0625;
         }
@@ -290,14 +293,14 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
       if (tid < ICX * ICY) {
         const int cj = tid / ICX, ci = tid - cj * ICX;
         // f - Iu Iv f = (f - Iv f) + Iv (f - Iu f): the second term is the v-interpolant (Lebesgue constant 1.25) of the
-        // u-errors on the stencil's FOUR node rows, so the horizontal-edge error is taken over all measured rows of the
-        // stencil (grid rows cj-1 .. cj+2 of this band), and likewise the vertical-edge error over its columns
+        // u-errors on the stencil's FOUR node rows, so the horizontal-edge error is taken over the four node rows of the
+        // stencil (node rows cj .. cj+3 of this band, each measured at its own midpoint), and likewise the vertical-edge
+        // error over its four node columns ci .. ci+3: no stencil line is extrapolated from a neighbour's measurement
         float eh = 0.f, ev = 0.f;
 #pragma unroll
-        for (int d = -1; d <= 2; ++d) {
-          const int r = min(max(cj + d, 0), ICY), c = min(max(ci + d, 0), ICX);
-          eh = nan_max(eh, errs[r * ICX + ci]);
-          ev = nan_max(ev, errs[I_HE + cj * (ICX + 1) + c]);
+        for (int d = 0; d < 4; ++d) {
+          eh = nan_max(eh, errs[(cj + d) * ICX + ci]);
+          ev = nan_max(ev, errs[I_HE + cj * IVC + ci + d]);
         }
         // float32 side of the bound, worst case, with u = 2^-24 and R = relmax (largest node value relative to the centre
         // node): a node is rounded to float32 (u R); the column combination is 4 roundings of partial sums <= 1.25 R (the
@@ -532,7 +535,8 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
 #pragma unroll
       for (int i = 0; i < WARP_MAX_PX; ++i) {
         const int ix = sxs[i] >> 5, iy = sys[i] >> 5, fx = sxs[i] & 31, fy = sys[i] & 31;
-        const bool inside = (int)((unsigned)(ix + 1) <= (unsigned)W) & (int)((unsigned)(iy + 1) <= (unsigned)H);   // footprint touches the image
+        const bool inside = (int)((unsigned)(ix + 1) <= (unsigned)W) & (int)((unsigned)(iy + 1) <= (unsigned)H) &
+                            (int)(warp_pixel(tid, i) < npx);      // footprint touches the image; slots beyond the band read byte 0
         const int idx = inside ? iy * tpitch + ix + cst : 0;       // byte 0: its four taps are border zeros
         const int a = lds[idx], b = lds[idx + 1], c = lds[idx + tpitch], d = lds[idx + tpitch + 1];
         const int acc = (a * ((32 - fy) * (32 - fx)) + b * ((32 - fy) * fx) + c * (fy * (32 - fx)) + d * (fy * fx)) * 32;
