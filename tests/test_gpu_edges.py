@@ -296,3 +296,46 @@ def test_fp32_few_pixel_kernel_bit_identical_to_halo_kernel(tmp_path):
     got = np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in sizes])
     want = np.load(out)
     assert np.isfinite(got).all() and np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+@pytest.mark.gpu
+def test_matrix_pipe_stem_bit_identical_to_vector_stem(tmp_path):
+    """The stem (conv 1 -> 32 + BN + ReLU + max-pool) runs on v_mfma_f32_32x32x2_f32 (stem_mfma_kernel: K = 9 padded to 10,
+    max-pool by DPP inside the accumulator quads); with UMT_STEM_VALU=1 (read once per process, hence the child process)
+    on the vector pipe.  The matrix instruction is the same k-ordered fmaf chain, so fp32 and bf16 backbone features must
+    agree bit for bit, and a NaN / inf pixel must poison exactly the same pooled pixels."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "valu.npy"
+    body = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from umetrack_amd import arch\n"
+        "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
+        "gm = model_from_state_dict(arch.make_synthetic_state(4)).to('cuda')\n"
+        "img = torch.rand(1030, 96, 96, generator=torch.Generator().manual_seed(78))\n"
+        "img[3, 0, 0] = float('nan'); img[5, 95, 95] = float('inf'); img[6, 40, 41] = float('nan'); img[1027, 57, 8] = float('nan')\n"
+        "res = []\n"
+        "for prec in ('fp32', 'bf16'):\n"
+        "    gm.precision = prec\n"
+        "    res += [gm.backbone(img[:k].cuda()).cpu().numpy() for k in (2, 70, 1030)]\n"
+        f"np.save({str(out)!r}, np.concatenate(res))\n")
+    subprocess.run([sys.executable, "-c", body], check=True, env=dict(os.environ, UMT_STEM_VALU="1"), timeout=110)
+    from umetrack_amd import arch
+    gm = model_from_state_dict(arch.make_synthetic_state(4)).to("cuda")
+    img = torch.rand(1030, 96, 96, generator=torch.Generator().manual_seed(78))
+    img[3, 0, 0] = float("nan")
+    img[5, 95, 95] = float("inf")
+    img[6, 40, 41] = float("nan")
+    img[1027, 57, 8] = float("nan")        # 1024 crops and more: a workgroup walks a crop's 12 bands (double-buffered rows)
+    res = []
+    for prec in ("fp32", "bf16"):
+        gm.precision = prec
+        res += [gm.backbone(img[:k].cuda()).cpu().numpy() for k in (2, 70, 1030)]
+    got, want = np.concatenate(res), np.load(out)
+    assert np.isnan(got).any() and np.isfinite(got[:2]).all()
+    assert np.array_equal(got, want, equal_nan=True), float(np.nanmax(np.abs(got - want)))

@@ -922,7 +922,8 @@ static int finalize_on_device(umt_model* m, int device) {
   for (const PackedSeq& p : packed_seq) p.layer->w16 = m->slab + p.off;   // sizes are multiples of 4 floats: 16-B aligned
   for (const PackedH& p : packed_h) p.layer->wh = m->slab_h + p.off;   // every size is a multiple of 8 bf16 = 16 B
   for (const PackedH& p : packed_x3) p.layer->wx3 = m->slab_h + p.off;
-  m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3]};
+  m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3],
+                       (m->conv_flags & CONV_STEM_VALU) ? 1 : 0};
   m->skel = SkelParams{m->slab + sk_off[0], m->slab + sk_off[1], m->slab + sk_off[2], m->slab + sk_off[3]};
   m->status = reinterpret_cast<int32_t*>(m->slab + status_off);
   return 0;

@@ -124,12 +124,234 @@ __global__ __launch_bounds__(256) void stem_kernel(StemParams p, const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------- matrix-pipe form
+// The same layer on v_mfma_f32_32x32x2_f32: K = 9 taps padded to 10, five instructions per tile of 32 convolution pixels
+// x 32 channels.  The instruction is an exact k-ordered fmaf chain starting from 0, so each output is the same chain
+// fma(w8, p8, ... fma(w1, p1, fma(w0, p0, 0))) the vector kernel above evaluates (the tenth slot multiplies 0 by 0):
+// results are BIT-IDENTICAL to it (tests/test_gpu_edges.py, UMT_STEM_VALU).  Measured per 4096 crops (bf16 output):
+// vector kernel 0.42-0.46 ms; this one 0.35-0.38 ms with the matrix pipe busy 49 % of it (rocprofv3 SQ_VALU_MFMA_BUSY):
+// the 0.17 ms of MFMA and the ~400 vector instructions per band and wave ADD on this chip rather than overlap, so what is
+// left to win is a shorter epilogue, not a better schedule.  How it got there (each step measured, 4096 crops):
+//  * a first form with the 2x2 window on four lanes spent as many vector instructions on DPP max as the vector kernel
+//    spends on FMAs: 0.64 ms;
+//  * operands swapped (weights as the row operand): a lane owns one convolution pixel and the 16 channels 8g + 4lh + e;
+//  * a wave works on PAIRS of tiles - the same 32 columns of the two convolution rows 2y and 2y + 1 - so the vertical
+//    half of the 2x2 max-pool and the ReLU are one v_max3(a, b, 0) per value with no lane traffic, and the horizontal
+//    half one DPP max with the neighbouring lane; BN comes before the max (a scale may be negative), as
+//    model_utils.py:119-124 orders the layers: 0.49 ms;
+//  * the epilogue of pair i issued behind the MFMAs of pair i + 1 (sched_group_barrier): 0.45 ms;
+//  * MFMA results in VGPRs (Makefile: -mllvm -amdgpu-mfma-vgpr-form for this file; 32 v_accvgpr_read per pair gone) and
+//    the DPP max as one instruction: 0.37 ms;
+//  * the two lanes of a column pair hold the same 16 channels; v_permlane32_swap arranges 8 contiguous channels per lane:
+//    one 16-byte store (bf16) per lane, a whole pixel per four lanes.
+typedef float stem_f32x16 __attribute__((ext_vector_type(16)));
+typedef float stem_f32x2 __attribute__((ext_vector_type(2)));
+
+// max with the neighbouring lane (quad_perm [1,0,3,2]) of eight values in place: one v_max_f32_dpp each.  (The builtin
+// form costs a DPP move, a canonicalising max and the max per value.)  Inline assembly is opaque to the compiler's hazard
+// recogniser, and a DPP read of a VGPR written by the preceding vector instruction needs two wait states: the s_nop.
+__device__ __forceinline__ void stem_pair_max8(float& a, float& b, float& c, float& d, float& e, float& f, float& g, float& h) {
+#define STEM_DPP(i) "v_max_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" STEM_DPP(0) STEM_DPP(1) STEM_DPP(2) STEM_DPP(3) STEM_DPP(4) STEM_DPP(5) STEM_DPP(6) STEM_DPP(7)
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+#undef STEM_DPP
+}
+
+// A workgroup walks `nb` consecutive bands of one crop with the next band's input rows in flight (one 16-byte load per
+// lane, held in registers, written to the other half of a double-buffered LDS tile before the band's last epilogue), so
+// no wave waits on HBM between bands; the constants are forced resident before the loop because the compiler's wait-count
+// pass otherwise carries their pending loads into the loop as vmcnt waits that drain every band's prefetch and stores.
+// Few-crop launches (the tracker's per-frame call) keep one band per workgroup for the parallelism.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const float* __restrict__ images, int n, int nb,
+                                                        void* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float sbuf[2][STEM_IN_ROWS * STEM_LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int per_img = (48 / STEM_ROWS) / nb;
+  const int img = blockIdx.x / per_img, band0 = (blockIdx.x - img * per_img) * nb;
+  const float* src = images + (size_t)img * 96 * 96;
+  // staging: lane tid < 240 owns float4 c4 of staged row r of every band (input row 8 band - 1 + r)
+  const int sr = tid / 24, sc4 = tid - sr * 24;
+  const bool stager = tid < STEM_IN_ROWS * 24;
+  auto row_ok = [&](int band) {
+    const int y = 2 * STEM_ROWS * band - 1 + sr;
+    return stager && y >= 0 && y < 96;
+  };
+  auto fetch = [&](int band) {                                // unconditional (a branch around a load costs a full vmcnt drain);
+    const int y = 2 * STEM_ROWS * band - 1 + sr;              // rows outside the crop are zeroed when staged
+    return *reinterpret_cast<const float4*>(src + (row_ok(band) ? y * 96 + 4 * sc4 : 0));
+  };
+  auto stage = [&](float* dstbuf, float4 v, bool ok) -> int {
+    if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (stager) {
+      float* d = dstbuf + sr * STEM_LDW + 2 + 4 * sc4;
+      *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
+    }
+    return !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+  };
+  if (tid < 2 * STEM_IN_ROWS) {
+    float* d = &sbuf[0][0] + tid * STEM_LDW;                  // both buffers: the two zero columns either side of a row
+    d[0] = d[1] = d[98] = d[99] = 0.f;
+  }
+  int bad = stage(sbuf[0], fetch(band0), row_ok(band0));
+  // weights of this lane's channel li for the taps 2j + lh (the tenth slot: 0), BN constants of its 16 channels
+  float wq[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) wq[j] = 2 * j + lh < 9 ? p.w[(2 * j + lh) * 32 + li] : 0.f;
+  float4 cb[4], cs[4], ch[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    cb[g] = *reinterpret_cast<const float4*>(p.bias + 8 * g + 4 * lh);
+    cs[g] = *reinterpret_cast<const float4*>(p.scale + 8 * g + 4 * lh);
+    ch[g] = *reinterpret_cast<const float4*>(p.shift + 8 * g + 4 * lh);
+  }
+  // float offset of each of the lane's five taps from its tile's origin in the staged rows (tap (ky, kx) of pixel (y, x):
+  // staged row y + ky, column x + kx + 1; the tenth slot reads the zero at the start of the tile's first row)
+  int toff[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int tap = 2 * j + lh, ky = tap / 3, kx = tap - 3 * ky;
+    toff[j] = tap < 9 ? ky * STEM_LDW + li + kx + 1 : -1;
+  }
+  const int px = li & 1;
+  // every constant has arrived before the band loop: the compiler's wait-count pass would otherwise carry their pending
+  // loads into the loop body as vmcnt waits that also drain each band's prefetch and stores
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    asm volatile("" ::"v"(cb[g].x), "v"(cb[g].y), "v"(cb[g].z), "v"(cb[g].w), "v"(cs[g].x), "v"(cs[g].y), "v"(cs[g].z), "v"(cs[g].w),
+                 "v"(ch[g].x), "v"(ch[g].y), "v"(ch[g].z), "v"(ch[g].w));
+  asm volatile("" ::"v"(wq[0]), "v"(wq[1]), "v"(wq[2]), "v"(wq[3]), "v"(wq[4]));
+  int any_bad = __syncthreads_or(bad);
+  const float zero_in = sbuf[0][0];
+
+#pragma unroll 1
+  for (int ib = 0; ib < nb; ++ib) {
+    const int band = band0 + ib, yo0 = band * STEM_ROWS;
+    const float* sin_ = sbuf[ib & 1];
+    const bool more = ib + 1 < nb;
+    const float4 nxt = fetch(more ? band + 1 : band);
+
+    // 12 tile pairs per band (4 pooled rows x 3 column blocks of 16 pooled pixels): wave w takes pooled row w
+    auto epilogue = [&](const stem_f32x16& aa, const stem_f32x16& ab, int ry, int tx, bool check) {
+      const int xo = tx * 16 + (li >> 1);
+      float r4[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const stem_f32x2 sb0 = {cb[g].x, cb[g].y}, sb1 = {cb[g].z, cb[g].w}, ss0 = {cs[g].x, cs[g].y}, ss1 = {cs[g].z, cs[g].w},
+                         sh0 = {ch[g].x, ch[g].y}, sh1 = {ch[g].z, ch[g].w};
+        const stem_f32x2 a0 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g], aa[4 * g + 1]} + sb0, ss0, sh0);
+        const stem_f32x2 a1 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g + 2], aa[4 * g + 3]} + sb1, ss1, sh1);
+        const stem_f32x2 b0 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g], ab[4 * g + 1]} + sb0, ss0, sh0);
+        const stem_f32x2 b1 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g + 2], ab[4 * g + 3]} + sb1, ss1, sh1);
+        r4[g][0] = fmaxf(fmaxf(a0.x, b0.x), 0.f);
+        r4[g][1] = fmaxf(fmaxf(a0.y, b0.y), 0.f);
+        r4[g][2] = fmaxf(fmaxf(a1.x, b1.x), 0.f);
+        r4[g][3] = fmaxf(fmaxf(a1.y, b1.y), 0.f);
+      }
+      stem_pair_max8(r4[0][0], r4[0][1], r4[0][2], r4[0][3], r4[1][0], r4[1][1], r4[1][2], r4[1][3]);
+      stem_pair_max8(r4[2][0], r4[2][1], r4[2][2], r4[2][3], r4[3][0], r4[3][1], r4[3][2], r4[3][3]);
+      float res[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) res[i][e] = px ? r4[2 + i][e] : r4[i][e];
+      if (check) {        // rare: a pooled pixel whose 4x4 patch holds a non-finite input is NaN, as torch makes it
+        bool nf = false;
+        const float* patch = sin_ + (2 * ry) * STEM_LDW + 2 * xo + 1;
+#pragma unroll
+        for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 4; ++dx) nf = nf || !isfinite(patch[dy * STEM_LDW + dx]);
+        if (nf)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) res[i][e] = __builtin_nanf("");
+      }
+      // the lane holds channels 8 (2 px + i) + 4 lh + {0..3} for i = 0, 1; v_permlane32_swap trades piece 1 of the lower
+      // half-wave for piece 0 of the upper, after which lane (li, lh) holds the 8 channels 8 (2 px + lh) + {0..7}: one
+      // contiguous store per lane, a whole 64- or 128-byte pixel per four lanes
+      const size_t pix = ((size_t)img * 48 + yo0 + ry) * 48 + xo;
+      const int c0 = 8 * (2 * px + lh);
+      typedef unsigned int stem_u32x2 __attribute__((ext_vector_type(2)));
+      if (OUT_BF16) {
+        const stem_u32x2 s0 = __builtin_amdgcn_permlane32_swap(stem_pack_bf16x2(res[0][0], res[0][1]), stem_pack_bf16x2(res[1][0], res[1][1]), false, false);
+        const stem_u32x2 s1 = __builtin_amdgcn_permlane32_swap(stem_pack_bf16x2(res[0][2], res[0][3]), stem_pack_bf16x2(res[1][2], res[1][3]), false, false);
+        *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(out) + pix * 32 + c0) = make_uint4(s0.x, s1.x, s0.y, s1.y);
+      } else {
+        stem_u32x2 sw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sw[e] = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, res[0][e]), __builtin_bit_cast(unsigned, res[1][e]), false, false);
+        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<float*>(out) + pix * 32 + c0);
+        dst[0] = make_uint4(sw[0].x, sw[1].x, sw[2].x, sw[3].x);
+        dst[1] = make_uint4(sw[0].y, sw[1].y, sw[2].y, sw[3].y);
+      }
+    };
+    // the two interleaved MFMA chains of a pair (column block tx)
+    auto chains = [&](int tx, stem_f32x16& aa, stem_f32x16& ab) {
+      const float* base = sin_ + (2 * wave) * STEM_LDW + 32 * tx;   // convolution row 2 (yo0 + wave): staged row 2 wave is its row above
+      float va[5], vb[5];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        va[j] = toff[j] >= 0 ? base[toff[j]] : zero_in;
+        vb[j] = toff[j] >= 0 ? base[STEM_LDW + toff[j]] : zero_in;
+      }
+      const stem_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0], va[0], zero, 0, 0, 0);
+      ab = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0], vb[0], zero, 0, 0, 0);
+#pragma unroll
+      for (int j = 1; j < 5; ++j) {
+        aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j], va[j], aa, 0, 0, 0);
+        ab = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j], vb[j], ab, 0, 0, 0);
+      }
+    };
+    if (any_bad) {        // uniform; the plain order
+#pragma unroll 1
+      for (int tx = 0; tx < 3; ++tx) {
+        stem_f32x16 aa, ab;
+        chains(tx, aa, ab);
+        epilogue(aa, ab, wave, tx, true);
+      }
+      if (more) bad = stage(sbuf[(ib + 1) & 1], nxt, row_ok(band + 1));
+    } else {              // the epilogue of a pair is issued behind the MFMAs of the next
+      stem_f32x16 a0, b0, a1, b1, a2, b2;
+      chains(0, a0, b0);
+      chains(1, a1, b1);
+      epilogue(a0, b0, wave, 0, false);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
+      chains(2, a2, b2);
+      epilogue(a1, b1, wave, 1, false);
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+      }
+      // the next band's rows into the other buffer (last read before the previous barrier) ahead of the last epilogue:
+      // the wait for the prefetch then leaves that epilogue's stores in flight
+      if (more) bad = stage(sbuf[(ib + 1) & 1], nxt, row_ok(band + 1));
+      epilogue(a2, b2, wave, 2, false);
+    }
+    if (more) any_bad = __syncthreads_or(bad);
+  }
+}
+
 template <bool OUT_BF16>
 static int launch_stem_any(const StemParams& p, const float* images, int n, void* out, hipStream_t stream) {
   UMT_REQUIRE(n > 0, UMT_ERR_INVALID, "stem: n = %d", n);
   const int64_t blocks = (int64_t)n * (48 / STEM_ROWS);
   UMT_REQUIRE(blocks < ((int64_t)1 << 31), UMT_ERR_INVALID, "stem: batch too large");
-  hipLaunchKernelGGL(stem_kernel<OUT_BF16>, dim3((unsigned)blocks), dim3(256), 0, stream, p, images, n, out);
+  const int nb = n >= 1024 ? 48 / STEM_ROWS : 1;             // bands per workgroup of the matrix-pipe form
+  if (p.valu)
+    hipLaunchKernelGGL(stem_kernel<OUT_BF16>, dim3((unsigned)blocks), dim3(256), 0, stream, p, images, n, out);
+  else
+    hipLaunchKernelGGL(stem_mfma_kernel<OUT_BF16>, dim3((unsigned)(blocks / nb)), dim3(256), 0, stream, p, images, n, nb, out);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -65,6 +65,7 @@ enum : unsigned {
   CONV_NO_S2P = 512u,       // UMT_CONV_NOS2P: fp32 fused stride-2 layers on the one-tile-per-workgroup kernel instead of the persistent one
   CONV_NO_DEPTH = 4096u,    // UMT_CONV_NODEPTH: bf16 stage 1 + the 32 -> 64 stride-2 layer as three launches instead of stage1_depth_bf16
   CONV_NO_SMALL = 8192u,    // UMT_CONV_NOSMALL: few-pixel fp32 launches on conv3x3s1_halo_f32<4,1,1,1> instead of conv_small.hip
+  CONV_STEM_VALU = 16384u,  // UMT_STEM_VALU: the stem on the vector pipe (stem_kernel) instead of stem_mfma_kernel
   CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
 };
 unsigned conv_flags_from_env();
@@ -172,6 +173,7 @@ struct StemParams {
   const float* bias;   // dev [32]
   const float* scale;  // dev [32]
   const float* shift;  // dev [32]
+  int valu;            // CONV_STEM_VALU: the vector-pipe kernel instead of the matrix-pipe one (bit-identical)
 };
 int launch_stem(const StemParams& p, const float* images, int n, float* out, hipStream_t stream);
 int launch_stem_bf16(const StemParams& p, const float* images, int n, uint16_t* out, hipStream_t stream);
