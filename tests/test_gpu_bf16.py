@@ -5,9 +5,14 @@ The reference has no reduced-precision mode, so nothing here is pinned to it ("p
     the same tensors (weights, stored activations) to bfloat16 and accumulates wide.  The two
     differ only by fp32 accumulation order and the 1-ulp bf16 roundings that order can flip,
     tolerance 1.5 % of the feature map's max magnitude;
-  * the cost of the mode is stated against the fp32 path on the golden sequence: wrist
-    translation within 1 mm, landmarks within 1.5 mm (fp32 parity mode holds 0.01 mm; bf16 carries
-    8 significant bits through 26 layers).  Use fp32 where the reference's numbers must be met.
+  * the cost of the mode is stated against the fp32 path.  It depends on the weights: over 8 weight
+    seeds on the BASELINE configs[2] batch the per-coordinate landmark difference has mean
+    0.19-0.68 mm, p99.9 0.81-4.43 mm and max 1.16-8.46 mm (profiles/r03_bf16_tolerance_8seeds.json,
+    tools/bf16_tolerance.py).  The stated tolerance is 1.5 x the worst seed - mean 1.0 mm, p99.9 6.6 mm,
+    max 12.7 mm (UmeTrackModel.BF16_LANDMARK_TOLERANCE_MM) - and is held here on two of those seeds
+    (the mildest and the worst); on the golden sequence (one seed) the wrist stays within 1 mm.
+    fp32 parity mode holds 0.01 mm; bf16 carries 8 significant bits through 26 layers.  Use fp32
+    where the reference's numbers must be met.
 """
 import numpy as np
 import pytest
@@ -99,6 +104,30 @@ def test_bf16_end_to_end_cost_on_golden_sequence(models, golden_sequence):
     assert worst_t < WRIST_TOL_M
     assert worst_a < ANGLE_TOL_RAD
     gm.reset_memory()
+
+
+@pytest.mark.parametrize("seed", [1, 3])
+def test_bf16_landmark_difference_within_stated_tolerance(seed):
+    """The stated tolerance (derived over 8 weight seeds at 8192 hand-frames) on a 1024-hand-frame batch of the same
+    synthetic workload, for the mildest (1) and the worst (3) of those seeds."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from umetrack_amd.lib.models.umetrack_model import UmeTrackModel
+    pipe = bench.Pipeline(512, 64, 512, seed=0, device=torch.device("cuda", 0), weight_seed=seed)
+    pipe.model.precision = "fp32"
+    pipe.step()
+    p32 = pipe.pred_lm.clone()
+    pipe.model.precision = "bf16"
+    pipe.step()
+    d = (pipe.pred_lm - p32).abs().reshape(-1).double()
+    tol = UmeTrackModel.BF16_LANDMARK_TOLERANCE_MM
+    got = {"mean": float(d.mean()), "p999": float(torch.quantile(d, 0.999)), "max": float(d.max())}
+    print(f"seed {seed}: bf16 vs fp32 landmarks {got} mm (stated {tol})")
+    assert torch.isfinite(pipe.pred_lm).all() and got["max"] > 0.0
+    for k in tol:
+        assert got[k] <= tol[k], (k, got, tol)
 
 
 @pytest.mark.parametrize("switch", ["UMT_CONV_NOTHIN", "UMT_CONV_NODEPTH"])

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -236,9 +237,15 @@ static void run(const char* name, K kern, double flop_per_wave, double mfma_per_
          waves_per_simd, flops / (ms * 1e-3) / 1e12, ms / reps, ticks / mfma_per_wave, ticks / (ms / reps * 1e3));
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* out;
   if (hipMalloc(&out, 256 * 2 * 256 * sizeof(float)) != hipSuccess) return 1;
+  if (argc > 1 && !strcmp(argv[1], "brief")) {     // what bench.py reads for frac_vs_sustained: two lines, under a second
+    run("bf16 32x32x16, 2x2 tile, operands from LDS", k_bf16_32_lds, (double)ITERS * 2 * 4 * 2.0 * 32 * 32 * 16, ITERS * 8.0, 2, out);
+    run("fp32 32x32x2, register operands", k_f32_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 2, ITERS * 8.0, 2, out);
+    (void)hipFree(out);
+    return 0;
+  }
   for (int w = 1; w <= 2; ++w) {
     run("bf16 32x32x16, register operands", k_bf16_32, (double)ITERS * 8 * 2.0 * 32 * 32 * 16, ITERS * 8.0, w, out);
     run("bf16 16x16x32, register operands", k_bf16_16, (double)ITERS * 16 * 2.0 * 16 * 16 * 32, ITERS * 16.0, w, out);

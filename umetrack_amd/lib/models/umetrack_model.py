@@ -116,6 +116,12 @@ class UmeTrackModel:
     def device(self) -> Optional[torch.device]:
         return self._device
 
+    # Stated tolerance of the "bf16" mode against the "fp32" mode, per landmark coordinate, in millimetres: 1.5 x the
+    # worst of 8 weight seeds on the BASELINE configs[2] batch (profiles/r03_bf16_tolerance_8seeds.json, made by
+    # tools/bf16_tolerance.py: per seed mean 0.19-0.68, p99.9 0.81-4.43, max 1.16-8.46 mm).  The cost of the mode depends
+    # on the weights; with trained weights it is re-derived by running that script.  tests/test_gpu_bf16.py holds it.
+    BF16_LANDMARK_TOLERANCE_MM = {"mean": 1.0, "p999": 6.6, "max": 12.7}
+
     @property
     def precision(self) -> str:
         """"fp32" (default, the reference's arithmetic), "bf16" (bf16 backbone activations and
