@@ -130,21 +130,24 @@ def test_bf16_landmark_difference_within_stated_tolerance(seed):
         assert got[k] <= tol[k], (k, got, tol)
 
 
-@pytest.mark.parametrize("switch", ["UMT_CONV_NOTHIN", "UMT_CONV_NODEPTH"])
+@pytest.mark.parametrize("switch", ["UMT_CONV_NOTHIN", "UMT_CONV_NODEPTH", "UMT_CONV_NOWALK"])
 def test_bf16_persistent_kernels_bit_identical_to_per_layer_kernels(models, tmp_path, switch):
     """By default stage 1 and the 32 -> 64 stride-2 layer run depth-first in ONE launch (stage1_depth.hip: role waves and
     LDS rings), stages 2-3 on the persistent kernels of conv_thin.hip.  UMT_CONV_NODEPTH=1 (read once per process, hence
     the child process) runs stage 1 as two fused BasicBlock launches + the fused stride-2 launch instead;
     UMT_CONV_NOTHIN=1 runs every layer on conv3x3s1_halo_bf16 / conv3x3s2_ds_bf16.  Same arithmetic order everywhere, so
     the backbone features must agree bit for bit: for 1 and 7 crops (one crop per workgroup, pipeline fill and drain
-    only), for 131 crops and for 300 (more crops than workgroups: crops streamed back to back through the rings)."""
+    only), for 131 crops and for 300 (more crops than workgroups: crops streamed back to back through the rings).
+    UMT_CONV_NOWALK=1 runs the 64 -> 128 stride-2 layer one tile per workgroup instead of on conv3x3s2_walk_bf16 (512
+    workgroups walking the tiles with the next tile's input rows in flight); that kernel takes over above 512 tiles:
+    675 at 300 crops (one or two tiles per workgroup), 2250 at 1000 crops (ragged walks of four and five tiles)."""
     import os
     import subprocess
     import sys
     gm, _ = models
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = tmp_path / "ref.npy"
-    sizes = (1, 7, 131, 300)
+    sizes = (1, 7, 131, 300) + ((1000,) if switch == "UMT_CONV_NOWALK" else ())
     child = (
         "import sys, numpy as np, torch\n"
         f"sys.path.insert(0, {root!r})\n"
@@ -152,11 +155,11 @@ def test_bf16_persistent_kernels_bit_identical_to_per_layer_kernels(models, tmp_
         "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
         f"gm = model_from_state_dict(arch.make_synthetic_state({int(gm_seed(models))})).to('cuda')\n"
         "gm.precision = 'bf16'\n"
-        "img = torch.rand(300, 96, 96, generator=torch.Generator().manual_seed(31))\n"
+        f"img = torch.rand({max(sizes)}, 96, 96, generator=torch.Generator().manual_seed(31))\n"
         f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in {sizes!r}]))\n")
     env = dict(os.environ, **{switch: "1"})
     subprocess.run([sys.executable, "-c", child], check=True, env=env, timeout=110)
-    img = torch.rand(300, 96, 96, generator=torch.Generator().manual_seed(31))
+    img = torch.rand(max(sizes), 96, 96, generator=torch.Generator().manual_seed(31))
     gm.precision = "bf16"
     try:
         got = np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in sizes])

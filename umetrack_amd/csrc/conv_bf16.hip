@@ -561,6 +561,256 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_bf16(ConvS2ArgsH g) {
   }
 }
 
+// The 64 -> 128 layer as a WALK: two workgroups per CU, each taking tiles t, t + grid, ... with the next tile's input
+// rows already in flight.  conv3x3s2_ds_bf16 gives every 64-pixel tile a workgroup of its own, whose 80 MFMAs per wave
+// (2.6 k cycles) follow an HBM round trip for the first chunk and most of another for the second, and whose epilogue's
+// constant loads queue behind them: 25 k ticks per tile, the matrix pipe 21 % busy (rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES;
+// phase stamps: tools/s2_stamps.py on a -DUMT_S2_STAMP=64 build).  What the stamps led to, in order:
+//  * a deeper weight ring (9 k-step slots, 8 ahead) changed nothing: the waits were not for weights;
+//  * a wave's loads return in order, so a weight fragment requested after a row load waits for HBM (chunk 0's nine taps:
+//    7.3 k ticks against 1.3 k of MFMA) and so do BN constants loaded in the epilogue (10.6 k ticks): the constants sit
+//    in LDS, and the rows of the next tile are requested after this tile's last weight load, in front of the epilogue
+//    (which loads nothing): taps 3.3 + 2.7 k, epilogue 5 k;
+//  * A fragments read one k-step ahead of their MFMAs: taps 2.6 + 2.5 k.
+// Measured per 4096 crops: 245 -> 225 us for this layer.  The same walk with four chunks per tile measured 216 us
+// against 202 us for the 128 -> 256 layer (chunks 2 and 3 have no slot in front of an epilogue) and is not dispatched.
+// Both layers move 0.6 / 0.3 GB of activations through HBM per launch (input once, two outputs): ~110 / 55 us at the
+// rate this chip sustains, so what is left here is overlap of the epilogue (6.7 k of a tile's 16.7 k ticks) with the
+// other workgroup's MFMAs, not arithmetic.  Same k order and epilogue arithmetic: bit-identical results.
+#ifdef UMT_S2_STAMP        // diagnostic builds only (tools/s2_stamps.py): s_memtime at the phase boundaries of one tile
+__device__ unsigned long long g_s2_stamp[64];     // [0..31] phases of one tile, [32..63] start of every tile of the workgroup
+#define S2STAMP_TILE() do { if (blockIdx.x == 5 && tid == 0 && iter < 31 && a.cin_s == UMT_S2_STAMP) { g_s2_stamp[32 + iter] = __builtin_amdgcn_s_memtime(); g_s2_stamp[33 + iter] = 0; } } while (0)
+#define S2STAMP(k) do { if (blockIdx.x == 5 && tid == 0 && iter == 1 && a.cin_s == UMT_S2_STAMP) g_s2_stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2STAMP(k) do {} while (0)
+#define S2STAMP_TILE() do {} while (0)
+#endif
+// epilogue of one 32 x 32 accumulator tile with the BN constants in LDS (no global load: a wave's loads return in order,
+// and one issued here would wait for the next tile's input rows already in flight)
+__device__ __forceinline__ void walk_store_tile(const f32x16& acc, float* patch, int lane, int mbase, int cobase, int M, int cout_s,
+                                                const float* cB, const float* cS, const float* cH, int relu, uint16_t* out) {
+  const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDP + li] = acc[r];
+  __builtin_amdgcn_wave_barrier();
+  const int q = lane & 3, rsub = lane >> 2;
+  const int co = cobase + 8 * q;
+  if (co < cout_s) {
+    const float4 cb0 = *reinterpret_cast<const float4*>(cB + co), cb1 = *reinterpret_cast<const float4*>(cB + co + 4);
+    const float4 cs0 = *reinterpret_cast<const float4*>(cS + co), cs1 = *reinterpret_cast<const float4*>(cS + co + 4);
+    const float4 ch0 = *reinterpret_cast<const float4*>(cH + co), ch1 = *reinterpret_cast<const float4*>(cH + co + 4);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = 16 * k + rsub;
+      const int m = mbase + row;
+      if (m < M) {
+        float4 v = *reinterpret_cast<const float4*>(patch + row * LDP + 8 * q);
+        float4 u = *reinterpret_cast<const float4*>(patch + row * LDP + 8 * q + 4);
+        affine4(v, cb0, cs0, ch0);
+        affine4(u, cb1, cs1, ch1);
+        if (relu) {
+          v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
+          u.x = relu1(u.x); u.y = relu1(u.y); u.z = relu1(u.z); u.w = relu1(u.w);
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)m * cout_s + co) =
+            make_uint4(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w), pack_bf16x2(u.x, u.y), pack_bf16x2(u.z, u.w));
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int S2W_ROW_BYTES = (S2H_ROWS_MAX + 1) * LDH * 2;      // staged rows + the zero row; the BN constants follow
+
+template <int TN, bool DS, int NCH>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_walk_bf16(ConvS2ArgsH g, int total, int ntn_shift) {
+  const ConvArgsH& a = g.c1;
+  constexpr int BM = S2H_BM, BN = 2 * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sAh[];   // rows x 80 B + one zero row (or the patches), constants
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int W = a.W, Wo = a.Wo, Ho = a.Ho;
+  const int c16_total = a.cin_s >> 4;
+  constexpr int nchunks = NCH;                                          // cin_s / 32 (host-checked)
+  const int zrow = S2H_ROWS_MAX;
+  int t = blockIdx.x;
+  if (t >= total) return;
+
+  auto centre = [&](int m) {
+    const int R = div_magic(m, Wo, a.mg_w), xo = m - R * Wo;
+    return 2 * W * R + 2 * xo;
+  };
+  auto geom = [&](int tt, int& m0, int& n0, int& g0, int& rows) {
+    const int tile_m = tt >> ntn_shift, tile_n = tt - (tile_m << ntn_shift);
+    m0 = tile_m * BM;
+    n0 = tile_n * BN;
+    const int m_last = min(m0 + BM, a.M) - 1;
+    g0 = centre(m0) - W - 1;
+    rows = centre(m_last) + W + 1 - g0 + 1;
+  };
+  if (tid < LDH * 2 / 16) *reinterpret_cast<uint4*>(sAh + zrow * LDH * 2 + 16 * tid) = make_uint4(0, 0, 0, 0);
+  float* sC = reinterpret_cast<float*>(sAh + S2W_ROW_BYTES);            // [c1, ds][bias, scale, shift][cout_w]
+  for (int i = tid; i < a.cout_w; i += 256) {
+    const bool in = i < a.cout_s;
+    sC[i] = in ? a.bias[i] : 0.f;
+    sC[a.cout_w + i] = in ? a.scale[i] : 0.f;
+    sC[2 * a.cout_w + i] = in ? a.shift[i] : 0.f;
+    if (DS) {
+      sC[3 * a.cout_w + i] = in ? g.ds_bias[i] : 0.f;
+      sC[4 * a.cout_w + i] = in ? g.ds_scale[i] : 0.f;
+      sC[5 * a.cout_w + i] = in ? g.ds_shift[i] : 0.f;
+    }
+  }
+
+  const unsigned wlane_off = (unsigned)(((size_t)lh * a.cout_w + wn * TN * 32 + li) * 16);
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t wblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(a.w), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t dblock = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(DS ? g.ds_w : a.w), 0, 0x7fffffff, 0x00020000);
+  const size_t w_c16 = (size_t)2 * a.cout_w * 16;
+  const size_t w_tap = (size_t)c16_total * w_c16;
+  uint4 bring[3][2][TN], bds[2][TN];
+  auto load_b = [&](uint4 (&dst)[2][TN], __amdgpu_buffer_rsrc_t blk, int tap, int chunk, int voff) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int c16 = min(chunk * 2 + c, c16_total - 1);
+      const int soff = (int)(tap * w_tap + c16 * w_c16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(blk, voff + j * 512, soff, 0);
+        dst[c][j] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+    }
+  };
+
+  constexpr int NLD = S2H_ROWS_MAX * 4 / 256;
+  uint4 ar0[NLD], ar1[NLD];
+  unsigned ok0 = 0, ok1 = 0;
+  auto load_a = [&](uint4 (&dst)[NLD], unsigned& okm, int g0, int rows, int chunk) {   // rows = 0: nothing to fetch
+    const int c0 = chunk * KCH;
+    okm = 0;
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+      const int idx = tid + 256 * k;
+      const int r = idx >> 2, q = idx & 3;
+      const int gp = g0 + r;
+      const bool ok = r < rows && gp >= 0 && (c0 + 8 * q) < a.cin_s;
+      const size_t off = ok ? (size_t)gp * a.cin_s + c0 + 8 * q : 0;
+      dst[k] = *reinterpret_cast<const uint4*>(a.in + off);
+      okm |= (ok ? 1u : 0u) << k;
+    }
+  };
+
+  int m0, n0, g0, rows;
+  geom(t, m0, n0, g0, rows);
+  int wvoff = (int)(n0 * 16 + wlane_off);
+  load_b(bring[0], wblock, 0, 0, wvoff);
+  load_b(bring[1], wblock, 1, 0, wvoff);
+  load_a(ar0, ok0, g0, rows, 0);
+  load_a(ar1, ok1, g0, rows, 1);
+
+  for (int iter = 0; t < total; t += gridDim.x, ++iter) {
+    S2STAMP(0);
+    S2STAMP_TILE();
+    int arow[9];
+    {
+      const int m = m0 + wm * 32 + li;
+      const bool live = m < a.M;
+      const int mm = live ? m : m0;
+      const int R = div_magic(mm, Wo, a.mg_w), xo = mm - R * Wo, yo = R - div_magic(R, Ho, a.mg_hw) * Ho;
+      const int base = 2 * W * R + 2 * xo - g0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = 2 * yo + ky - 1, xx = 2 * xo + kx - 1;
+          const bool ok = live && yy >= 0 && yy < a.H && xx >= 0 && xx < W;
+          arow[ky * 3 + kx] = ((ok ? base + (ky - 1) * W + (kx - 1) : zrow) * LDH + 8 * lh) * 2;
+        }
+    }
+    f32x16 acc[TN], accd[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; accd[j][r] = 0.f; }
+
+    const int tn = t + (int)gridDim.x;
+    const bool has_next = tn < total;
+    int m0n = m0, n0n = n0, g0n = g0, rowsn = 0;
+    if (has_next) geom(tn, m0n, n0n, g0n, rowsn);
+    const int wvoff_n = (int)(n0n * 16 + wlane_off);
+
+    // Where the input rows are requested: the NEXT tile's two chunks after this tile's last weight load, in front of
+    // the epilogue.  (NCH = 4, measured and not dispatched: chunks 2 and 3 are requested as soon as their register set
+    // is free, and the weights behind them wait once.)
+    auto step = [&](uint4 (&ar)[NLD], unsigned& okm, int chunk) {
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int idx = tid + 256 * k;
+        uint4 v = ar[k];
+        if (!((okm >> k) & 1u)) v = make_uint4(0, 0, 0, 0);
+        if ((idx >> 2) < rows) *reinterpret_cast<uint4*>(sAh + ((idx >> 2) * LDH + 8 * (idx & 3)) * 2) = v;
+      }
+      S2STAMP(1 + 4 * chunk);
+      __syncthreads();
+      S2STAMP(2 + 4 * chunk);
+      if (chunk + 2 < nchunks) load_a(ar, okm, g0, rows, chunk + 2);       // (compile-time condition)
+      const bool last = chunk + 1 >= nchunks;
+      // the A fragment of a k-step (tap, 16-channel group) is read one step ahead of its MFMAs
+      uint4 av[2];
+      av[0] = *reinterpret_cast<const uint4*>(sAh + arow[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap < 7) load_b(bring[(tap + 2) % 3], wblock, tap + 2, chunk, wvoff);
+        else load_b(bring[(tap + 2) % 3], wblock, tap - 7, last ? 0 : chunk + 1, last ? wvoff_n : wvoff);
+        if (DS && tap == 2) load_b(bds, dblock, 0, chunk, wvoff);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int ks = tap * 2 + c;
+          if (ks + 1 < 18) av[(ks + 1) & 1] = *reinterpret_cast<const uint4*>(sAh + arow[(ks + 1) >> 1] + ((ks + 1) & 1) * 32);
+          __builtin_amdgcn_sched_barrier(0);
+          const bf16x8 a8 = __builtin_bit_cast(bf16x8, av[ks & 1]);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, bring[tap % 3][c][j]), acc[j], 0, 0, 0);
+          if (DS && tap == 4) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              accd[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8, bds[c][j]), accd[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      S2STAMP(3 + 4 * chunk);
+      __syncthreads();
+      S2STAMP(4 + 4 * chunk);
+    };
+#pragma unroll
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+      step(ar0, ok0, chunk);
+      step(ar1, ok1, chunk + 1);
+    }
+    load_a(ar0, ok0, g0n, rowsn, 0);       // rowsn = 0 after the last tile: nothing is fetched
+    load_a(ar1, ok1, g0n, rowsn, 1);
+    float* patch = reinterpret_cast<float*>(sAh) + wave * 32 * LDP;
+    const int cw = a.cout_w;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      walk_store_tile(acc[j], patch, lane, m0 + wm * 32, n0 + wn * TN * 32 + j * 32, a.M, a.cout_s, sC, sC + cw, sC + 2 * cw, a.relu,
+                      reinterpret_cast<uint16_t*>(a.out));
+    if (DS) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        walk_store_tile(accd[j], patch, lane, m0 + wm * 32, n0 + wn * TN * 32 + j * 32, a.M, a.cout_s, sC + 3 * cw, sC + 4 * cw,
+                        sC + 5 * cw, 0, g.ds_out);
+    }
+    S2STAMP(20);
+    __syncthreads();                 // the patches alias the staged rows
+    S2STAMP(21);
+    m0 = m0n; n0 = n0n; g0 = g0n; rows = rowsn; wvoff = wvoff_n;
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 static void launch_gather_h(const ConvArgsH& a, hipStream_t stream) {
   constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
@@ -613,6 +863,10 @@ int launch_conv_bf16(const ConvLayer& L, const uint16_t* in, int n, int h, int w
   return 0;
 }
 
+#ifdef UMT_S2_STAMP
+extern "C" void umt_s2_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s2_stamp), sizeof(g_s2_stamp)); }
+#endif
+
 int launch_conv_s2_fused_bf16(const ConvLayer& c1, const ConvLayer* ds, const uint16_t* in, int n, int h, int w,
                               uint16_t* out, uint16_t* ds_out, hipStream_t stream) {
   UMT_REQUIRE(conv_s2_fused_applicable(c1, ds, h, w) && c1.cin_s % 16 == 0, UMT_ERR_INVALID, "conv_s2_bf16: layer shapes not supported");
@@ -634,6 +888,17 @@ int launch_conv_s2_fused_bf16(const ConvLayer& c1, const ConvLayer* ds, const ui
   if (lds < patch) lds = patch;
   const bool wide = c1.cout_w % 128 == 0;
   dim3 grid((a.M + S2H_BM - 1) / S2H_BM, c1.cout_w / (wide ? 128 : 64));
+  const bool no_walk = (c1.flags & CONV_NO_WALK) != 0;
+  if (wide && !no_walk && !a.out_f32 && a.cin_s == 64 && (grid.y & (grid.y - 1)) == 0 && (int64_t)grid.x * grid.y > 512) {
+    int shift = 0;
+    while ((1u << shift) < grid.y) ++shift;
+    const int total = (int)(grid.x * grid.y);
+    const size_t lds_w = (size_t)S2W_ROW_BYTES + (size_t)6 * a.cout_w * sizeof(float);
+    void (*kw)(ConvS2ArgsH, int, int) = ds ? conv3x3s2_walk_bf16<2, true, 2> : conv3x3s2_walk_bf16<2, false, 2>;
+    hipLaunchKernelGGL(kw, dim3(512), dim3(256), lds_w, stream, g, total, shift);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   void (*kern)(ConvS2ArgsH) = wide ? (ds ? conv3x3s2_ds_bf16<2, true> : conv3x3s2_ds_bf16<2, false>)
                                    : (ds ? conv3x3s2_ds_bf16<1, true> : conv3x3s2_ds_bf16<1, false>);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, g);
