@@ -539,6 +539,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
   };
 
   if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + zrow * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* sC = sA + (S2_ROWS_MAX + 1) * LDA;              // [conv1, down-sample][bias, scale, shift][cout_w]
+  for (int i = tid; i < a.cout_w; i += 256) {
+    const bool in = i < a.cout_s;
+    sC[i] = in ? a.bias[i] : 0.f;
+    sC[a.cout_w + i] = in ? a.scale[i] : 0.f;
+    sC[2 * a.cout_w + i] = in ? a.shift[i] : 0.f;
+    if (DS) {
+      sC[3 * a.cout_w + i] = in ? g.ds_bias[i] : 0.f;
+      sC[4 * a.cout_w + i] = in ? g.ds_scale[i] : 0.f;
+      sC[5 * a.cout_w + i] = in ? g.ds_shift[i] : 0.f;
+    }
+  }
 
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -629,6 +641,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
       }
       __syncthreads();
       const bool last_chunk = chunk + 1 == nchunks;
+      // the A fragment of a step (tap, 8-channel group) is read one step ahead of its MFMAs
+      float4 avr[2];
+      avr[0] = *reinterpret_cast<const float4*>(sA + arow[0]);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         if (tap < 8) load_b(bnext, wblock, tap + 1, chunk, voff);
@@ -639,7 +654,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const float4 av = *reinterpret_cast<const float4*>(sA + arow[tap] + c * 8);
+          const int st = tap * 4 + c;
+          if (st + 1 < 36) avr[(st + 1) & 1] = *reinterpret_cast<const float4*>(sA + arow[(st + 1) >> 2] + ((st + 1) & 3) * 8);
+          const float4 av = avr[st & 1];
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
             acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bcur[c][j].x, acc[0][j], 0, 0, 0);
@@ -668,12 +685,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
     // after it would wait for all of it in the in-order load counter), and arrives under the two epilogues
     if (has_next) load_a(nxt, 0);
 
+    // the BN constants come from LDS: a global load here would wait for the input range just requested (a wave's loads
+    // return in order) and put an HBM round trip between the last MFMA and the first store of every tile
     float* patch = sA + wave * 32 * LDA;
-    epilogue<1, TN, false>(acc, patch, lane, cur.m0 + wm * 32, cur.n0 + wn * TN * 32, a);
+    const float4 no_res[4] = {};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cobase = cur.n0 + wn * TN * 32 + j * 32;
+      const int co = min(cobase + 4 * (lane & 7), a.cout_w - 4);
+      const float4 kc[3] = {*reinterpret_cast<const float4*>(sC + co), *reinterpret_cast<const float4*>(sC + a.cout_w + co),
+                            *reinterpret_cast<const float4*>(sC + 2 * a.cout_w + co)};
+      store_tile<false, true>(acc[0][j], no_res, patch, lane, cur.m0 + wm * 32, cobase, a, kc);
+    }
     if (DS) {
       ConvArgs d = a;
-      d.bias = g.ds_bias; d.scale = g.ds_scale; d.shift = g.ds_shift; d.out = g.ds_out; d.relu = 0; d.residual = nullptr;
-      epilogue<1, TN, false>(accd, patch, lane, cur.m0 + wm * 32, cur.n0 + wn * TN * 32, d);
+      d.out = g.ds_out; d.relu = 0; d.residual = nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cobase = cur.n0 + wn * TN * 32 + j * 32;
+        const int co = min(cobase + 4 * (lane & 7), a.cout_w - 4);
+        const float4 kc[3] = {*reinterpret_cast<const float4*>(sC + 3 * a.cout_w + co), *reinterpret_cast<const float4*>(sC + 4 * a.cout_w + co),
+                              *reinterpret_cast<const float4*>(sC + 5 * a.cout_w + co)};
+        store_tile<false, true>(accd[0][j], no_res, patch, lane, cur.m0 + wm * 32, cobase, d, kc);
+      }
     }
     __syncthreads();          // the patches alias the staging area the next tile is about to fill
     cur = nxt;
@@ -772,14 +806,16 @@ unsigned conv_flags_from_env() {
   return f;
 }
 
+constexpr size_t S2P_CONST_BYTES_MAX = 6 * 512 * sizeof(float);      // BN constants of both convolutions, cout_w <= 512
+
 int conv_prepare_device() {
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, false>), lds));
   UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2_ds_f32<1, true>), lds));
-  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<1, false>), lds));
-  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<1, true>), lds));
-  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, false>), lds));
-  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, true>), lds));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<1, false>), lds + S2P_CONST_BYTES_MAX));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<1, true>), lds + S2P_CONST_BYTES_MAX));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, false>), lds + S2P_CONST_BYTES_MAX));
+  UMT_TRY(raise_dynamic_lds(reinterpret_cast<const void*>(conv3x3s2p_ds_f32<2, true>), lds + S2P_CONST_BYTES_MAX));
   UMT_TRY(conv_x3_prepare_device());
   UMT_TRY(conv_chain_prepare_device());
   UMT_TRY(stage1_depth_prepare_device());
@@ -815,7 +851,7 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
   // 64 x 64 workgroup tiles (one 32x32 tile per wave and convolution): wider cout tiles would need the
   // weight double buffers of both convolutions for two tiles and spill
-  if (!(c1.flags & CONV_NO_S2P)) {
+  if (!(c1.flags & CONV_NO_S2P) && c1.cout_w <= 512) {
     // persistent kernel: 64 x 128 tiles where cout allows, two workgroups per CU walking their XCD's tiles
     const bool wide = false;      // TN = 2 needs both whole-tap buffers for two tiles: spills (measured 2x slower)
     const int tiles_m = (a.M + S2_BM - 1) / S2_BM, tiles_n = c1.cout_w / (wide ? 128 : 64);
@@ -823,7 +859,7 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
     const unsigned wgs = (unsigned)(ntiles < 512 ? (ntiles + 7) / 8 * 8 : 512);
     void (*pk)(ConvS2Args, int, int) = wide ? (ds ? conv3x3s2p_ds_f32<2, true> : conv3x3s2p_ds_f32<2, false>)
                                             : (ds ? conv3x3s2p_ds_f32<1, true> : conv3x3s2p_ds_f32<1, false>);
-    hipLaunchKernelGGL(pk, dim3(wgs), dim3(256), lds, stream, g, tiles_m, tiles_n);
+    hipLaunchKernelGGL(pk, dim3(wgs), dim3(256), lds + (size_t)6 * c1.cout_w * sizeof(float), stream, g, tiles_m, tiles_n);
     UMT_CHECK_HIP(hipGetLastError());
     return 0;
   }
