@@ -38,3 +38,11 @@ timeout -k 10 300 python3 $ROOT/bench.py > $OUT/bench_fp32.json 2> $OUT/bench_fp
 timeout -k 10 300 python3 $ROOT/bench.py --precision bf16 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
 timeout -k 10 300 python3 $ROOT/bench.py --precision fp32x3 > $OUT/bench_fp32x3.json 2> $OUT/bench_fp32x3.err
 cut -c1-200 $OUT/bench_fp32.json; cut -c1-200 $OUT/bench_bf16.json; cut -c1-200 $OUT/bench_fp32x3.json
+# 6. the bare-loop matrix-pipe probe (the sustained ceilings frac_vs_sustained refers to)
+timeout -k 10 120 $ROOT/tools/bin/mfma_peak > $OUT/mfma_peak.txt 2>&1
+grep -E "LDS|fp32" $OUT/mfma_peak.txt | head -4
+# 7. the per-frame tracker path: kernel stats of 256 frames (2 hands, 4 crops per frame), fp32 and bf16
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/pf_track -o p --output-format csv -- python3 $ROOT/tools/per_frame_prof.py plain 256 > $OUT/per_frame_fp32.txt 2>&1
+timeout -k 10 120 python3 $ROOT/tools/per_frame_prof.py plain 256 > $OUT/per_frame_plain_fp32.txt 2>/dev/null
+UMT_PF_PREC=bf16 timeout -k 10 120 python3 $ROOT/tools/per_frame_prof.py plain 256 > $OUT/per_frame_plain_bf16.txt 2>/dev/null
+cat $OUT/per_frame_plain_fp32.txt $OUT/per_frame_plain_bf16.txt

@@ -11,6 +11,11 @@ for P in fp32 bf16 fp32x3; do
   [ -s gpurun_out/rp/mfma_busy_$P.txt ] && cp gpurun_out/rp/mfma_busy_$P.txt profiles/${R}_mfma_busy_$P.txt
 done
 cp gpurun_out/rp/stage_roofline.jsonl profiles/${R}_stage_roofline_host_timed.jsonl
+[ -s gpurun_out/rp/mfma_peak.txt ] && cp gpurun_out/rp/mfma_peak.txt profiles/${R}_mfma_peak.txt
+if [ -d gpurun_out/rp/pf_track ]; then
+  cp $(find gpurun_out/rp/pf_track -name '*kernel_stats.csv' | head -1) profiles/${R}_per_frame_kernel_stats.csv
+  { echo "per-frame tracker path, 256 frames x 2 hands (tools/per_frame_prof.py plain 256; second line = measured pass):"; echo "fp32:"; cat gpurun_out/rp/per_frame_plain_fp32.txt; echo "bf16:"; cat gpurun_out/rp/per_frame_plain_bf16.txt; } > profiles/${R}_per_frame_ms.txt
+fi
 python3 - <<PY
 import json
 f=json.load(open('gpurun_out/rp/traffic_fp32.json')); b=json.load(open('gpurun_out/rp/traffic_bf16.json')); x=json.load(open('gpurun_out/rp/traffic_fp32x3.json'))
