@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Phase stamps of conv3x3s2_walk_bf16 (diagnostic library built with -DUMT_S2_STAMP=<cin>; experiments only):
-  python tools/s2_stamps.py tools/bin/libumt_s2_STAMP64.so"""
+"""Phase stamps of conv3x3s2_walk_bf16 (library built with -DUMT_S2_STAMP=<cin>) or conv3x3s2p_ds_f32 (-DUMT_S2P_STAMP=<cin>);
+experiments only:  python tools/s2_stamps.py tools/bin/libumt_s2_STAMP64.so [bf16|fp32]"""
 import ctypes
 import os
 import sys
@@ -15,7 +15,7 @@ nat.LIB_PATH = os.path.join(ROOT, sys.argv[1])          # before the first nat.l
 from umetrack_amd.lib.models.model_loader import model_from_state_dict  # noqa: E402
 
 gm = model_from_state_dict(arch.make_synthetic_state(0)).to("cuda")
-gm.precision = "bf16"
+gm.precision = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 img = torch.rand(4096, 96, 96, device="cuda")
 for _ in range(3):
     gm.backbone(img)
@@ -24,12 +24,12 @@ L = nat.lib()
 st = (ctypes.c_ulonglong * 64)()
 L.umt_s2_stamps.argtypes = [ctypes.c_void_p]
 L.umt_s2_stamps(st)
-print("conv3x3s2_walk_bf16, second tile of workgroup 5, wave 0 (s_memtime ticks, 100 MHz x ? - relative):")
+print("second tile of workgroup 5, wave 0 (s_memtime ticks):")
 names = {0: "tile start"}
 for c in range(4):
     names.update({1 + 4 * c: f"chunk {c}: rows written", 2 + 4 * c: f"chunk {c}: barrier", 3 + 4 * c: f"chunk {c}: load issue + 9 taps",
                   4 + 4 * c: f"chunk {c}: barrier"})
-names.update({20: "epilogues", 21: "barrier"})
+names.update({17: "next tile rows requested", 18: "epilogue conv1", 20: "epilogue(s)", 21: "barrier"})
 prev = st[0]
 for k in sorted(names):
     if st[k]:

@@ -504,6 +504,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
 #ifndef UMT_S2P_ATAP
 #define UMT_S2P_ATAP 0
 #endif
+#ifdef UMT_S2P_STAMP       // diagnostic builds only (tools/s2_stamps.py): s_memtime at the phase boundaries of one tile
+__device__ unsigned long long g_s2p_stamp[64];
+#define S2PSTAMP(k) do { if (blockIdx.x == 5 && tid == 0 && iter == 1 && a.cin_s == UMT_S2P_STAMP) g_s2p_stamp[k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" void umt_s2_stamps(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_s2p_stamp), sizeof(g_s2p_stamp)); }
+#else
+#define S2PSTAMP(k) do {} while (0)
+#endif
 template <int TN, bool DS>
 __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int tiles_m, int tiles_n) {
   const ConvArgs& a = g.c1;
@@ -603,7 +610,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
   int voff = (int)(cur.n0 * 16 + wlane_off);
   load_b(bcur, wblock, 0, 0, voff);
 
-  for (; t < t_hi; t += wgs_per_xcd) {
+  for (int iter = 0; t < t_hi; t += wgs_per_xcd, ++iter) {
+    S2PSTAMP(0);
+#ifdef UMT_S2P_STAMP
+    if (blockIdx.x == 5 && tid == 0 && iter < 31 && a.cin_s == UMT_S2P_STAMP) { g_s2p_stamp[32 + iter] = __builtin_amdgcn_s_memtime(); g_s2p_stamp[33 + iter] = 0; }
+#endif
     const bool has_next = t + wgs_per_xcd < t_hi;
     Tile nxt = cur;
     if (has_next) nxt = tile_of(t + wgs_per_xcd);
@@ -639,7 +650,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
         if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
         if ((idx >> 3) < arows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
       }
+      S2PSTAMP(1 + 4 * chunk);
       __syncthreads();
+      S2PSTAMP(2 + 4 * chunk);
       const bool last_chunk = chunk + 1 == nchunks;
       // the A fragment of a step (tap, 8-channel group) is read one step ahead of its MFMAs
       float4 avr[2];
@@ -679,11 +692,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
 #pragma unroll
           for (int j = 0; j < TN; ++j) bcur[c][j] = bnext[c][j];
       }
+      S2PSTAMP(3 + 4 * chunk);
       __syncthreads();
+      S2PSTAMP(4 + 4 * chunk);
     }
     // the next tile's input range is requested here, behind the last weight load of this tile (a weight fragment requested
     // after it would wait for all of it in the in-order load counter), and arrives under the two epilogues
     if (has_next) load_a(nxt, 0);
+    // (phase stamps of a 32 -> 64 tile, tools/s2_stamps.py on a -DUMT_S2P_STAMP=32 build: 30.5 k ticks of which rows
+    // written 3.8 k, the nine taps 11.1 k = the MFMA time, next rows requested 2.8 k, the two epilogues 3.8 + 8 k - the
+    // stores of 32 KB per tile wait on a memory system that all 512 workgroups load at 3 TB/s; starting the second
+    // workgroup of every CU half a tile late changed nothing)
+    S2PSTAMP(17);
 
     // the BN constants come from LDS: a global load here would wait for the input range just requested (a wave's loads
     // return in order) and put an HBM round trip between the last MFMA and the first store of every tile
@@ -697,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
                             *reinterpret_cast<const float4*>(sC + 2 * a.cout_w + co)};
       store_tile<false, true>(acc[0][j], no_res, patch, lane, cur.m0 + wm * 32, cobase, a, kc);
     }
+    S2PSTAMP(18);
     if (DS) {
       ConvArgs d = a;
       d.out = g.ds_out; d.relu = 0; d.residual = nullptr;
@@ -709,7 +730,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s2p_ds_f32(ConvS2Args g, int ti
         store_tile<false, true>(accd[0][j], no_res, patch, lane, cur.m0 + wm * 32, cobase, d, kc);
       }
     }
+    S2PSTAMP(20);
     __syncthreads();          // the patches alias the staging area the next tile is about to fill
+    S2PSTAMP(21);
     cur = nxt;
     voff = voff_next;
   }
