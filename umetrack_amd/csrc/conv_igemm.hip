@@ -819,7 +819,7 @@ unsigned conv_flags_from_env() {
   static const struct { const char* name; unsigned bit; } kSwitches[] = {
       {"UMT_CONV_NOTHIN", CONV_NO_THIN},         {"UMT_CONV_NOFUSE", CONV_NO_FUSE}, {"UMT_CONV_NOSTREAM128", CONV_NO_STREAM128},
       {"UMT_CONV_NOTHIN_F32", CONV_NO_THIN_F32}, {"UMT_CONV_GATHER", CONV_GATHER},  {"UMT_CONV_NOS2", CONV_NO_S2},
-      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOWIDE", CONV_NO_WIDE}, {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}, {"UMT_CONV_NOS2P", CONV_NO_S2P},
+      {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}, {"UMT_CONV_NOS2P", CONV_NO_S2P},
       {"UMT_CONV_NOPIPE32", CONV_NO_PIPE32},      {"UMT_CONV_NOPIPE64", CONV_NO_PIPE64},
       {"UMT_CONV_NODEPTH", CONV_NO_DEPTH},        {"UMT_CONV_NOSMALL", CONV_NO_SMALL},
       {"UMT_STEM_VALU", CONV_STEM_VALU},          {"UMT_CONV_NOWALK", CONV_NO_WALK}};

@@ -67,7 +67,6 @@ enum : unsigned {
   CONV_NO_SMALL = 8192u,    // UMT_CONV_NOSMALL: few-pixel fp32 launches on conv3x3s1_halo_f32<4,1,1,1> instead of conv_small.hip
   CONV_STEM_VALU = 16384u,  // UMT_STEM_VALU: the stem on the vector pipe (stem_kernel) instead of stem_mfma_kernel
   CONV_NO_WALK = 32768u,    // UMT_CONV_NOWALK: bf16 fused stride-2 layers one tile per workgroup instead of conv3x3s2_walk_bf16
-  CONV_NO_WIDE = 128u,      // UMT_CONV_NOWIDE: bf16 128/256-channel layers on the round-1 kernels instead of conv_wide.hip
 };
 unsigned conv_flags_from_env();
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
