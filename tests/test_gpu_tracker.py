@@ -156,6 +156,49 @@ def test_track_frame_one_host_sync_and_cached_landmarks(monkeypatch):
             assert other is not pose.landmarks_mm
 
 
+def test_tracker_staging_block_across_frame_shapes():
+    """The tracker keeps ONE pinned staging block whose pixel part only grows.  A tracker that has seen 640x480 views and
+    is then given 320x240 views (other cameras, other pitch, fewer bytes), and then large ones again, must return exactly
+    what a fresh tracker returns for each of those frames (no history: first-frame results are comparable)."""
+    from umetrack_amd.lib.common import camera
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.tracker.tracker import HandTracker, HandTrackerOpts, InputFrame, ViewData
+    from umetrack_amd.lib.tracker.tracking_result import SingleHandPose
+    rng = np.random.default_rng(29)
+    hm = load_generic_hand_model()
+    state = arch.make_synthetic_state(5)
+    big = _rig_cameras(rng)
+    small = [camera.Fisheye62CameraModel(c.width // 2, c.height // 2, tuple(np.asarray(c.f) / 2), tuple(np.asarray(c.c) / 2),
+                                         list(c.distort), c.camera_to_world_xf) for c in big]
+    gt = {}
+    for h in (0, 1):
+        W = np.eye(4, dtype=np.float32)
+        W[:3, :3] = synthetic.random_rotations(rng, 1)[0]
+        W[:3, 3] = (rng.uniform(-60, 60), rng.uniform(-40, 40), rng.uniform(380, 480))
+        gt[h] = SingleHandPose(joint_angles=np.zeros(22, np.float32), wrist_xform=W, hand_confidence=1.0)
+
+    def frame_for(cams):
+        img = rng.integers(0, 256, size=(cams[0].height, cams[0].width * 4)).astype(np.uint8)
+        mv = img.reshape(cams[0].height, 4, -1)
+        return InputFrame(views=[ViewData(image=mv[:, v, :], camera=cams[v], camera_angle=0.0) for v in range(4)])
+
+    seq = [(big, frame_for(big)), (small, frame_for(small)), (big, frame_for(big)), (small, frame_for(small))]
+    walker = HandTracker(model_from_state_dict(state), HandTrackerOpts())
+    for cams, frame in seq:
+        crop_cams = walker.gen_crop_cameras(cams, [0.0] * 4, hm, gt, min_num_crops=1)
+        walker.reset_history(clear_model_memory=True)
+        got = walker.track_frame(frame, hm, crop_cams)
+        fresh = HandTracker(model_from_state_dict(state), HandTrackerOpts())
+        want = fresh.track_frame(frame, hm, crop_cams)
+        assert set(got.hand_poses) == set(want.hand_poses) == {0, 1}
+        for h in (0, 1):
+            assert np.array_equal(got.hand_poses[h].joint_angles, want.hand_poses[h].joint_angles)
+            assert np.array_equal(got.hand_poses[h].wrist_xform, want.hand_poses[h].wrist_xform)
+            assert np.array_equal(got.hand_poses[h].landmarks_mm, want.hand_poses[h].landmarks_mm)
+            assert np.isfinite(got.hand_poses[h].landmarks_mm).all()
+
+
 def test_scale_calibration_head_through_tracker(hand_model_np):
     from umetrack_amd.lib.common.hand import load_generic_hand_model
     from umetrack_amd.lib.models.model_loader import model_from_state_dict
