@@ -272,7 +272,9 @@ def test_fp32_few_pixel_kernel_bit_identical_to_halo_kernel(tmp_path):
     conv_small.hip (16x16x4 matrix instructions, k-slots in the channel order of four 32x32x2 instructions); with
     UMT_CONV_NOSMALL=1 (read once per process, hence the child process) on conv3x3s1_halo_f32<4,1,1,1>.  Same chain per
     output, so the backbone features must agree bit for bit: 1, 4 and 13 crops (ragged 16-pixel tiles), and 40 crops,
-    where the 64-channel layers are past the switch-over and the 256-channel layers are not."""
+    where the 64-channel layers are past the switch-over and the 256-channel layers are not.  The regressor's four 3x3
+    layers (80 -> 76 channels padded to 96: the last workgroup along cout has two waves without channels) take the same
+    kernel for few hands: its 62 raw outputs for 1, 2 and 5 hands, both heads, must agree bit for bit too."""
     import os
     import subprocess
     import sys
@@ -288,12 +290,32 @@ def test_fp32_few_pixel_kernel_bit_identical_to_halo_kernel(tmp_path):
         "from umetrack_amd.lib.models.model_loader import model_from_state_dict\n"
         "gm = model_from_state_dict(arch.make_synthetic_state(3)).to('cuda')\n"
         "img = torch.rand(40, 96, 96, generator=torch.Generator().manual_seed(77))\n"
-        f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in {sizes!r}]))\n")
+        "from types import SimpleNamespace as NS\n"
+        "g = torch.Generator().manual_seed(79)\n"
+        "tmp = torch.randn(5, 72, 6, 6, generator=g); E0 = torch.eye(4).repeat(5, 1, 1); hidx = torch.tensor([0, 1, 1, 0, 1])\n"
+        "skel = NS(joint_rotation_axes=torch.randn(5, 22, 3, generator=g), joint_rest_positions=torch.randn(5, 22, 3, generator=g) * 0.05)\n"
+        "raws = []\n"
+        "for k in (1, 2, 5):\n"
+        "    sk = NS(joint_rotation_axes=skel.joint_rotation_axes[:k], joint_rest_positions=skel.joint_rest_positions[:k])\n"
+        "    raws.append(gm.regress_decode(0, tmp[:k], E0[:k], hidx[:k], sk)[1].cpu().numpy().ravel())\n"
+        "    raws.append(gm.regress_decode(1, tmp[:k], E0[:k], hidx[:k])[1].cpu().numpy().ravel())\n"
+        f"np.save({str(out)!r}, np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy().ravel() for k in {sizes!r}] + raws))\n")
     subprocess.run([sys.executable, "-c", body], check=True, env=dict(os.environ, UMT_CONV_NOSMALL="1"), timeout=110)
     from umetrack_amd import arch
     gm = model_from_state_dict(arch.make_synthetic_state(3)).to("cuda")
     img = torch.rand(40, 96, 96, generator=torch.Generator().manual_seed(77))
-    got = np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy() for k in sizes])
+    from types import SimpleNamespace as NS
+    g = torch.Generator().manual_seed(79)
+    tmp = torch.randn(5, 72, 6, 6, generator=g)
+    E0 = torch.eye(4).repeat(5, 1, 1)
+    hidx = torch.tensor([0, 1, 1, 0, 1])
+    skel = NS(joint_rotation_axes=torch.randn(5, 22, 3, generator=g), joint_rest_positions=torch.randn(5, 22, 3, generator=g) * 0.05)
+    raws = []
+    for k in (1, 2, 5):
+        sk = NS(joint_rotation_axes=skel.joint_rotation_axes[:k], joint_rest_positions=skel.joint_rest_positions[:k])
+        raws.append(gm.regress_decode(0, tmp[:k], E0[:k], hidx[:k], sk)[1].cpu().numpy().ravel())
+        raws.append(gm.regress_decode(1, tmp[:k], E0[:k], hidx[:k])[1].cpu().numpy().ravel())
+    got = np.concatenate([gm.backbone(img[:k].cuda()).cpu().numpy().ravel() for k in sizes] + raws)
     want = np.load(out)
     assert np.isfinite(got).all() and np.array_equal(got, want), float(np.abs(got - want).max())
 

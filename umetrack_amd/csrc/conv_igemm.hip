@@ -791,7 +791,7 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
     // configuration); with UMT_CONV_NOSMALL one 32x32 tile per wave.  The k order per output is the same in all
     // three, so results are bit-identical.
     const int64_t wide_wgs = ((M + 127) / 128) * (L.cout_w % 128 == 0 ? L.cout_w / 128 : 1);
-    const bool few = wide_wgs < 64 && (L.cout_w % 128 == 0 || L.cout_w == 64);
+    const bool few = wide_wgs < 64 && (L.cout_w % 128 == 0 || L.cout_w == 64 || L.cout_w == 96);
     if (few && conv_small_applicable(a, (L.flags & CONV_NO_SMALL) != 0)) launch_conv_small(a, stream);   // 16x16x4 tiles (conv_small.hip)
     else if (few) launch_halo<4, 1, 1, 1>(a, stream);
     else if (L.cout_w % 128 == 0) launch_halo<2, 2, 2, 2>(a, stream);

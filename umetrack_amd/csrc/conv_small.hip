@@ -21,7 +21,11 @@ template <bool RES>
 __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sA[];   // (16 + 2W + 2) rows x LDA + one zero row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * SM_BM, n0 = blockIdx.y * SM_BN + wave * 16;
+  const int m0 = blockIdx.x * SM_BM, n0w = blockIdx.y * SM_BN + wave * 16;
+  // cout_w = 96 (the regressor's 3x3 layers): the last workgroup along cout has two waves without channels; they stage
+  // and synchronise with the others, compute on channel 0's weights and store nothing
+  const bool has_channels = n0w < a.cout_w;
+  const int n0 = has_channels ? n0w : 0;
   const int ks = lane >> 4, lc = lane & 15;                    // k-slot; pixel (B operand) / output channel (A operand) of this lane
   const int W = a.W, H = a.H;
   const int rows = SM_BM + 2 * W + 2;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
                ch = *reinterpret_cast<const float4*>(a.shift + coc);
   const int mout = m0 + lc;
   float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (RES && mout < a.M && co < a.cout_s) rr = *reinterpret_cast<const float4*>(a.residual + (size_t)mout * a.cout_s + co);
+  if (RES && has_channels && mout < a.M && co < a.cout_s) rr = *reinterpret_cast<const float4*>(a.residual + (size_t)mout * a.cout_s + co);
 
   // A staging as conv3x3s1_halo_f32: slot idx = tid + 256 k (row idx >> 3, channel quad idx & 7), next chunk prefetched
   constexpr int NLD = (SM_BM + 2 * 48 + 2) * 8 / 256 + 1;      // W <= 48
@@ -111,19 +115,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
       if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
     }
     __syncthreads();
+    // the eight operand values of a tap are read one tap ahead of its MFMAs (the chain is dependent: a read waited for in
+    // its own tap leaves the matrix pipe idle for the LDS latency, nine times per chunk)
+    float pa[2][8];
+    auto read_tap = [&](float (&dst)[8], int tap) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dst[2 * c] = *reinterpret_cast<const float*>(sAb + arow[tap] + c * 32);
+        dst[2 * c + 1] = *reinterpret_cast<const float*>(sAb + arow[tap] + c * 32 + 8);
+      }
+    };
+    read_tap(pa[0], 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap < 8) load_b(bnext, tap + 1, chunk);
       else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
       if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      if (tap < 8) read_tap(pa[(tap + 1) & 1], tap + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (chunk * 4 + c >= c8_total) continue;               // zero channel groups past the end (cin_s = 80): skipped, as the halo kernel's one-tile form
-        const float p1 = *reinterpret_cast<const float*>(sAb + arow[tap] + c * 32);
-        const float p2 = *reinterpret_cast<const float*>(sAb + arow[tap] + c * 32 + 8);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].x, p1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].y, p2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].x, pa[tap & 1][2 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].y, pa[tap & 1][2 * c + 1], acc, 0, 0, 0);
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
     __syncthreads();
   }
 
-  if (mout < a.M && co < a.cout_s) {
+  if (has_channels && mout < a.M && co < a.cout_s) {
     float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
     v.x = (v.x + cb.x) * cs.x + ch.x;
     v.y = (v.y + cb.y) * cs.y + ch.y;
@@ -149,11 +163,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
 }
 
 bool conv_small_applicable(const ConvArgs& a, bool force_off) {
-  return !force_off && a.taps == 9 && a.stride == 1 && a.W <= 48 && a.cout_w % SM_BN == 0 && a.cin_s % 8 == 0;
+  return !force_off && a.taps == 9 && a.stride == 1 && a.W <= 48 && a.cout_w % 32 == 0 && a.cin_s % 8 == 0;
 }
 
 void launch_conv_small(const ConvArgs& a, hipStream_t stream) {
-  dim3 grid((a.M + SM_BM - 1) / SM_BM, a.cout_w / SM_BN);
+  dim3 grid((a.M + SM_BM - 1) / SM_BM, (a.cout_w + SM_BN - 1) / SM_BN);
   const size_t lds = (size_t)(SM_BM + 2 * a.W + 2 + 1) * LDA * sizeof(float);
   if (a.residual)
     hipLaunchKernelGGL(conv3x3s1_small_f32<true>, grid, dim3(256), lds, stream, a);
