@@ -5,6 +5,8 @@
 #include "../umetrack_amd/csrc/conv_thin.hip"
 #include "../umetrack_amd/csrc/conv_x3.hip"
 #include "../umetrack_amd/csrc/conv_chain.hip"
+#include "../umetrack_amd/csrc/conv_small.hip"
+#include "../umetrack_amd/csrc/stage1_depth.hip"
 #include <vector>
 #include <stdio.h>
 #include <string.h>
