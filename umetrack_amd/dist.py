@@ -52,7 +52,14 @@ def shard_recordings(lengths: Sequence[int], world: int) -> List[List[int]]:
 def all_reduce_partials(partials: torch.Tensor) -> torch.Tensor:
     """Sum the float64[108] metric partials over all ranks (in place); identity for one process."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(partials, op=dist.ReduceOp.SUM)
+        if partials.is_cuda and dist.get_backend() != "nccl":
+            # a CPU backend (gloo rehearsals on a GPU host): reduce a host copy; gloo's own handling of device tensors
+            # stalled when two ranks shared one GPU
+            host = partials.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            partials.copy_(host)
+        else:
+            dist.all_reduce(partials, op=dist.ReduceOp.SUM)
     return partials
 
 
