@@ -175,7 +175,9 @@ def test_fused_1x1_chains_bit_identical_to_three_launches(bs, monkeypatch):
     (csrc/conv_chain.hip: operands swapped, a layer's accumulator registers are the next layer's operand).  With
     UMT_CONV_NOCHAIN=1 (read per model handle at umt_model_create) they run as three conv_igemm_f32 launches.  Same k
     order and epilogue arithmetic: fused features, temporal output and the memory state left behind must agree bit for
-    bit; bs = 1 and 37 leave the last 32-pixel wave tile ragged (36 and 1332 rows)."""
+    bit; bs = 1 and 37 leave the last 32-pixel wave tile ragged (36 and 1332 rows) and take the few-rows form
+    (conv1x1_chain3_small_f32: a workgroup per 32-row tile, a wave per cout tile, layers exchanged through LDS), bs = 256
+    (288 tiles) the persistent one."""
     import torch
     from umetrack_amd.lib.models.model_loader import model_from_state_dict
     g = torch.Generator().manual_seed(100 + bs)

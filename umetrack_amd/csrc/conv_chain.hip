@@ -162,6 +162,103 @@ __global__ __launch_bounds__(CHAIN_THREADS, 1) void conv1x1_chain3_f32(Chain3Arg
   }
 }
 
+// ---------------------------------------------------------------------------------------- few rows
+// The tracker's per-frame call has 72 rows (2 hands x 6 x 6).  In the kernel above one wave then walks its 32 rows
+// through all three layers and all of a layer's cout tiles in turn: 288 + 168 + 108 dependent MFMAs (17 us) after 114 KB
+// of weights went to LDS for three waves to use once - 32 us per launch.  Here a workgroup of four waves takes ONE
+// 32-row tile, wave t computes cout tile t of every layer (72 + 56 + 36 MFMAs), the weight fragments come straight from
+// L2 two channel groups ahead, and a layer's output crosses to the other waves through a 16 KB LDS tile (two barriers).
+// Per output the same k-ordered chain and the same epilogue expression as above: bit-identical (tests/test_gpu_edges.py).
+constexpr int CHAIN_SMALL_LD = 132;          // floats per LDS row: up to 128 channels + 4 (rows 4 banks apart)
+
+template <int KG, int NT, typename Opnd>
+__device__ __forceinline__ void chain_small_layer(const float* w, const float* bias, const float* scale, const float* shift, int relu,
+                                                  int t, int li, int lh, Opnd opnd, float4 (&out)[4]) {
+  // packed weights [g][half][NT * 32][4]: lane (li, lh) of cout tile t
+  const float* wl = w + ((size_t)lh * (NT * 32) + t * 32 + li) * 4;
+  constexpr int GS = 2 * NT * 32 * 4;        // floats per channel group
+  float4 wr[3];
+  wr[0] = *reinterpret_cast<const float4*>(wl);
+  if (KG > 1) wr[1] = *reinterpret_cast<const float4*>(wl + GS);
+  float4 cb[4], cs[4], ch[4];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const int co = t * 32 + 8 * gq + 4 * lh;
+    cb[gq] = *reinterpret_cast<const float4*>(bias + co);
+    cs[gq] = *reinterpret_cast<const float4*>(scale + co);
+    ch[gq] = *reinterpret_cast<const float4*>(shift + co);
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int g = 0; g < KG; ++g) {
+    if (g + 2 < KG) wr[(g + 2) % 3] = *reinterpret_cast<const float4*>(wl + (size_t)(g + 2) * GS);
+    const float4 x = opnd(g);
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 wv = wr[g % 3];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, x.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, x.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, x.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, x.w, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {            // the arithmetic of chain_epilogue
+    float4 v = make_float4(acc[4 * gq], acc[4 * gq + 1], acc[4 * gq + 2], acc[4 * gq + 3]);
+    v.x = (v.x + cb[gq].x) * cs[gq].x + ch[gq].x;
+    v.y = (v.y + cb[gq].y) * cs[gq].y + ch[gq].y;
+    v.z = (v.z + cb[gq].z) * cs[gq].z + ch[gq].z;
+    v.w = (v.w + cb[gq].w) * cs[gq].w + ch[gq].w;
+    if (relu) {
+      v.x = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.x), 0));
+      v.y = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.y), 0));
+      v.z = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.z), 0));
+      v.w = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v.w), 0));
+    }
+    out[gq] = v;
+  }
+}
+
+template <int K0G, int N0T, int K1G, int N1T, int K2G, int N2T>
+__global__ __launch_bounds__(256) void conv1x1_chain3_small_f32(Chain3Args a) {
+  static_assert(N0T <= 4 && N1T <= 4 && N2T <= 4, "one wave per cout tile");
+  __shared__ __attribute__((aligned(16))) float sH[2][32 * CHAIN_SMALL_LD];
+  const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m = blockIdx.x * 32 + li;
+  const bool live = m < a.M;
+  float4 q[4];
+  if (t < N0T) {
+    const float* row = a.in + (size_t)(live ? m : a.M - 1) * a.cin_s0 + 4 * lh;
+    float4 xin[K0G];
+#pragma unroll
+    for (int g = 0; g < K0G; ++g) xin[g] = *reinterpret_cast<const float4*>(row + 8 * g);
+    chain_small_layer<K0G, N0T>(a.w[0], a.bias[0], a.scale[0], a.shift[0], a.relu[0], t, li, lh, [&](int g) { return xin[g]; }, q);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<float4*>(&sH[0][li * CHAIN_SMALL_LD + t * 32 + 8 * gq + 4 * lh]) = q[gq];
+  }
+  __syncthreads();
+  if (t < N1T) {
+    chain_small_layer<K1G, N1T>(a.w[1], a.bias[1], a.scale[1], a.shift[1], a.relu[1], t, li, lh,
+                                [&](int g) { return *reinterpret_cast<const float4*>(&sH[0][li * CHAIN_SMALL_LD + 8 * g + 4 * lh]); }, q);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) *reinterpret_cast<float4*>(&sH[1][li * CHAIN_SMALL_LD + t * 32 + 8 * gq + 4 * lh]) = q[gq];
+  }
+  __syncthreads();
+  if (t < N2T) {
+    chain_small_layer<K2G, N2T>(a.w[2], a.bias[2], a.scale[2], a.shift[2], a.relu[2], t, li, lh,
+                                [&](int g) { return *reinterpret_cast<const float4*>(&sH[1][li * CHAIN_SMALL_LD + 8 * g + 4 * lh]); }, q);
+    if (live) {
+      float* orow = a.out + (size_t)m * a.cout_s2 + 4 * lh;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        if (t * 32 + 8 * gq + 4 * lh < a.cout_s2) *reinterpret_cast<float4*>(orow + t * 32 + 8 * gq) = q[gq];
+    }
+  }
+}
+
+constexpr int CHAIN_SMALL_MAX_TILES = 256;   // up to 8192 rows (227 hands): one 32-row tile per workgroup
+
 template <int K0G, int N0T, int K1G, int N1T, int K2G, int N2T>
 static constexpr size_t chain_lds_bytes() {
   return (size_t)(chain_w_floats<K0G, N0T>() + chain_w_floats<K1G, N1T>() + chain_w_floats<K2G, N2T>() + 3 * 32 * (N0T + N1T + N2T)) *
@@ -204,9 +301,15 @@ int launch_conv_chain3(const ConvLayer& l0, const ConvLayer& l1, const ConvLayer
   a.n_wave_tiles = (int)((rows + 31) / 32);
   a.cin_s0 = l0.cin_s;
   a.cout_s2 = l2.cout_s;
+  const bool temporal = chain_shape<UMT_CHAIN_TEMPORAL>(l0, l1, l2);
+  if (a.n_wave_tiles <= CHAIN_SMALL_MAX_TILES && !(l0.flags & CONV_NO_SMALL)) {
+    void (*ks)(Chain3Args) = temporal ? conv1x1_chain3_small_f32<UMT_CHAIN_TEMPORAL> : conv1x1_chain3_small_f32<UMT_CHAIN_FUSION>;
+    hipLaunchKernelGGL(ks, dim3((unsigned)a.n_wave_tiles), dim3(256), 0, stream, a);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   const int wgs = (a.n_wave_tiles + CHAIN_THREADS / 64 - 1) / (CHAIN_THREADS / 64);
   const dim3 grid((unsigned)(wgs < 256 ? wgs : 256));     // one persistent workgroup per CU (gfx950: 256 CUs)
-  const bool temporal = chain_shape<UMT_CHAIN_TEMPORAL>(l0, l1, l2);
   void (*kern)(Chain3Args) = temporal ? conv1x1_chain3_f32<UMT_CHAIN_TEMPORAL> : conv1x1_chain3_f32<UMT_CHAIN_FUSION>;
   const size_t lds = temporal ? chain_lds_bytes<UMT_CHAIN_TEMPORAL>() : chain_lds_bytes<UMT_CHAIN_FUSION>();
   hipLaunchKernelGGL(kern, grid, dim3(CHAIN_THREADS), lds, stream, a);
