@@ -2,7 +2,7 @@
 # kernel stats of one bench run, head-side kernels only (GPU box)
 cd /tmp; export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/hs; rm -rf $OUT; mkdir -p $OUT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT -o b --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-hands 0 --no-pcie > $OUT/bench.json 2> $OUT/bench.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT -o b --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --cpu-hands 0 --no-pcie --no-x3 --per-frame-frames 0 > $OUT/bench.json 2> $OUT/bench.err || exit 1
 python3 - <<PY
 import csv,glob
 f=glob.glob('$OUT/**/*kernel_stats.csv',recursive=True)[0]
