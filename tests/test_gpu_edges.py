@@ -274,7 +274,9 @@ def test_fp32_few_pixel_kernel_bit_identical_to_halo_kernel(tmp_path):
     conv_small.hip (16x16x4 matrix instructions, k-slots in the channel order of four 32x32x2 instructions); with
     UMT_CONV_NOSMALL=1 (read once per process, hence the child process) on conv3x3s1_halo_f32<4,1,1,1>.  Same chain per
     output, so the backbone features must agree bit for bit: 1, 4 and 13 crops (ragged 16-pixel tiles), and 40 crops,
-    where the 64-channel layers are past the switch-over and the 256-channel layers are not.  The regressor's four 3x3
+    where the 64-channel layers are past the switch-over and the 256-channel layers are not.  The three fused stride-2
+    launches take conv3x3s2_small_f32 up to 16 384 pixel x cout-tile units (1, 4 and 13 crops) and conv3x3s2p_ds_f32 beyond
+    (40 crops); the same switch selects between them.  The regressor's four 3x3
     layers (80 -> 76 channels padded to 96: the last workgroup along cout has two waves without channels) take the same
     kernel for few hands: its 62 raw outputs for 1, 2 and 5 hands, both heads, must agree bit for bit too."""
     import os

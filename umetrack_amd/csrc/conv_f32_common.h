@@ -26,6 +26,16 @@ struct ConvArgs {
   unsigned mg_hw, mg_w;   // floor(2^32 / (H*W)) + 1 and floor(2^32 / W) + 1 (division by multiplication)
 };
 
+// fused stride-2 conv1 + down-sample launches (conv3x3s2_ds_f32, conv3x3s2p_ds_f32, conv3x3s2_small_f32)
+struct ConvS2Args {
+  ConvArgs c1;        // conv1: in, w, epilogue constants, out; H, W, Ho, Wo, cin_s, cout_s, cout_w, relu, M
+  const float* ds_w;  // down-sample: packed [1][cin_s/8][2][cout_w][4], or null
+  const float* ds_bias;
+  const float* ds_scale;
+  const float* ds_shift;
+  float* ds_out;
+};
+
 // floor(m / d) for 0 <= m < 2^31 and 1 <= d <= 65536 with mg = floor(2^32 / d) + 1: the estimate is exact or one too high
 __device__ __forceinline__ int div_magic32(int m, int d, unsigned mg) {
   int q = (int)__umulhi((unsigned)m, mg);

@@ -337,14 +337,6 @@ __global__ __launch_bounds__(256, (TM * TN == 1 ? UMT_F32_MINB_1TILE : 2)) void 
 constexpr int S2_BM = 64;            // output pixels per workgroup: 2 waves along pixels x 2 along cout
 constexpr int S2_ROWS_MAX = 448;     // staged input rows (host checks 2W*ceil(63/Wo) + 3W + 1 <= this)
 
-struct ConvS2Args {
-  ConvArgs c1;        // conv1: in, w, epilogue constants, out; H, W, Ho, Wo, cin_s, cout_s, cout_w, relu, M
-  const float* ds_w;  // down-sample: packed [1][cin_s/8][2][cout_w][4], or null
-  const float* ds_bias;
-  const float* ds_scale;
-  const float* ds_shift;
-  float* ds_out;
-};
 
 template <int TN, bool DS>
 __global__ __launch_bounds__(256, 2) void conv3x3s2_ds_f32(ConvS2Args g) {
@@ -758,6 +750,8 @@ static void launch_cfg(const ConvArgs& a, hipStream_t stream) {
 
 bool conv_small_applicable(const ConvArgs& a, bool force_off);      // conv_small.hip
 void launch_conv_small(const ConvArgs& a, hipStream_t stream);
+bool conv_s2_small_applicable(const ConvS2Args& g, bool force_off);
+void launch_conv_s2_small(const ConvS2Args& g, hipStream_t stream);
 
 int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const float* residual,
                 float* out, hipStream_t stream) {
@@ -874,6 +868,11 @@ int launch_conv_s2_fused(const ConvLayer& c1, const ConvLayer* ds, const float* 
   const size_t lds = (size_t)(S2_ROWS_MAX + 1) * LDA * sizeof(float);
   // 64 x 64 workgroup tiles (one 32x32 tile per wave and convolution): wider cout tiles would need the
   // weight double buffers of both convolutions for two tiles and spill
+  if (conv_s2_small_applicable(g, (c1.flags & CONV_NO_SMALL) != 0)) {      // few pixels: 16x16x4 tiles (conv_small.hip)
+    launch_conv_s2_small(g, stream);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (!(c1.flags & CONV_NO_S2P) && c1.cout_w <= 512) {
     // persistent kernel: 64 x 128 tiles where cout allows, two workgroups per CU walking their XCD's tiles
     const bool wide = false;      // TN = 2 needs both whole-tap buffers for two tiles: spills (measured 2x slower)
