@@ -86,11 +86,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
 
   // A staging as conv3x3s1_halo_f32: slot idx = tid + 256 k (row idx >> 3, channel quad idx & 7), next chunk prefetched
   constexpr int NLD = (SM_BM + 2 * 48 + 2) * 8 / 256 + 1;      // W <= 48
-  float4 areg[NLD];
-  unsigned aok = 0;
-  auto load_a = [&](int chunk) {
+  // two register sets: a chunk's rows are requested two chunks before they are staged (a chunk is 72 MFMAs, about 1.2 us:
+  // less than the trip to another XCD's L2 where the previous launch left them)
+  float4 areg[2][NLD];
+  unsigned aok[2] = {0, 0};
+  auto load_a = [&](float4 (&dst)[NLD], unsigned& okm, int chunk) {      // past the last chunk: every slot reads offset 0
     const int c0 = chunk * KC;
-    aok = 0;
+    okm = 0;
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int idx = tid + 256 * k;
@@ -98,20 +100,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
       const int g = g0 + r;
       const bool ok = r < rows && g >= 0 && g < a.M && (c0 + 4 * q) < a.cin_s;
       const size_t off = ok ? (size_t)g * a.cin_s + c0 + 4 * q : 0;
-      areg[k] = *reinterpret_cast<const float4*>(a.in + off);
-      aok |= (ok ? 1u : 0u) << k;
+      dst[k] = *reinterpret_cast<const float4*>(a.in + off);
+      okm |= (ok ? 1u : 0u) << k;
     }
   };
-  load_a(0);
+  load_a(areg[0], aok[0], 0);
+  load_a(areg[1], aok[1], 1);
 
   f32x4s acc = {0.f, 0.f, 0.f, 0.f};
   const char* sAb = reinterpret_cast<const char*>(sA);
-  for (int chunk = 0; chunk < nchunks; ++chunk) {
+  auto step = [&](float4 (&ar)[NLD], unsigned& okm, int chunk) {
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int idx = tid + 256 * k;
-      float4 v = areg[k];
-      if (!((aok >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = ar[k];
+      if (!((okm >> k) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((idx >> 3) < rows) *reinterpret_cast<float4*>(sA + (idx >> 3) * LDA + 4 * (idx & 7)) = v;
     }
     __syncthreads();
@@ -129,8 +132,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap < 8) load_b(bnext, tap + 1, chunk);
-      else if (chunk + 1 < nchunks) load_b(bnext, 0, chunk + 1);
-      if (tap == 0 && chunk + 1 < nchunks) load_a(chunk + 1);
+      else load_b(bnext, 0, min(chunk + 1, nchunks - 1));       // (after the last chunk: a harmless re-read)
+      if (tap == 8) load_a(ar, okm, chunk + 2);                 // behind the chunk's last weight load
       if (tap < 8) read_tap(pa[(tap + 1) & 1], tap + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -143,6 +146,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
       for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
     }
     __syncthreads();
+  };
+  for (int chunk = 0; chunk < nchunks; chunk += 2) {
+    step(areg[0], aok[0], chunk);
+    if (chunk + 1 < nchunks) step(areg[1], aok[1], chunk + 1);
   }
 
   if (has_channels && mout < a.M && co < a.cout_s) {
