@@ -10,6 +10,7 @@
 // epilogue expression.  Results are bit-identical to that kernel's (tests/test_gpu_edges.py), as head_seq.hip's use of
 // the same instruction is to the head's 32x32x2 kernels.
 #include "conv_f32_common.h"
+#include <type_traits>
 
 namespace umt {
 
@@ -53,18 +54,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
   }
   if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + rows * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // weights: lane reads packed[tap][c8][h = ks & 1][n0 + lc][0..3] and uses elements (ks >> 1) and (ks >> 1) + 2, one tap
-  // ahead of the MFMAs.  (Measured and dropped: the whole next chunk in flight as 72 four-byte loads per lane - slower,
-  // 0.94 against 0.86 ms per frame: four waves x 16 output channels each pull the full weight stream through the CU's one
-  // texture path.  What these launches want next is 64 pixels x 16 output channels per workgroup with the weights
-  // staged once in LDS: an eighth of the traffic.)
+  // weights: lane reads packed[tap][c8][h = ks & 1][n0 + lc][0..3] and uses elements (ks >> 1) and (ks >> 1) + 2, three
+  // taps ahead of the MFMAs through a ring of four taps (a tap is 8 MFMAs = 0.3 k cycles, an L2 round trip two to three of
+  // them; one tap ahead: 13.1 us per launch, three: 12.6).  (Measured and dropped: the whole next chunk in flight as 72
+  // four-byte loads per lane - slower; half-width loads as a timing experiment - no change: not bound by the texture path.)
   typedef float f32x4v __attribute__((ext_vector_type(4)));
   typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, 0x7fffffff, 0x00020000);
   const int wvoff = (int)((((size_t)(ks & 1) * a.cout_w + n0 + lc) * 4) * sizeof(float));
   const size_t w_c8 = (size_t)2 * a.cout_w * 4 * sizeof(float), w_tap = (size_t)c8_total * w_c8;
   const bool hi = (ks >> 1) != 0;
-  float2 bcur[4], bnext[4];
+  float2 bring[4][4];                                          // ring of taps, three ahead of the MFMAs
   auto load_b = [&](float2 (&dst)[4], int tap, int chunk) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
       dst[c] = hi ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
     }
   };
-  load_b(bcur, 0, 0);
+  load_b(bring[0], 0, 0);
+  load_b(bring[1], 1, 0);
+  load_b(bring[2], 2, 0);
 
   // epilogue constants of the lane's four output channels n0 + 4 ks + {0..3}
   const int co = n0 + 4 * ks;
@@ -109,7 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
 
   f32x4s acc = {0.f, 0.f, 0.f, 0.f};
   const char* sAb = reinterpret_cast<const char*>(sA);
-  auto step = [&](float4 (&ar)[NLD], unsigned& okm, int chunk) {
+  auto step = [&](float4 (&ar)[NLD], unsigned& okm, int chunk, auto parc) {
+    constexpr int PAR = decltype(parc)::value;                 // chunk & 3 (9 taps per chunk: the ring slot of a tap depends on it)
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
       const int idx = tid + 256 * k;
@@ -131,25 +134,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
     read_tap(pa[0], 0);
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      if (tap < 8) load_b(bnext, tap + 1, chunk);
-      else load_b(bnext, 0, min(chunk + 1, nchunks - 1));       // (after the last chunk: a harmless re-read)
+      {   // global tap index T = 9 chunk + tap; slot T % 4 (chunk parity fixed per call of step: PAR)
+        const int T3 = tap + 3;
+        if (T3 < 9) load_b(bring[(PAR * 9 + T3) & 3], T3, chunk);
+        else load_b(bring[(PAR * 9 + T3) & 3], T3 - 9, min(chunk + 1, nchunks - 1));     // (after the last chunk: a harmless re-read)
+      }
       if (tap == 8) load_a(ar, okm, chunk + 2);                 // behind the chunk's last weight load
       if (tap < 8) read_tap(pa[(tap + 1) & 1], tap + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (chunk * 4 + c >= c8_total) continue;               // zero channel groups past the end (cin_s = 80): skipped, as the halo kernel's one-tile form
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].x, pa[tap & 1][2 * c], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bcur[c].y, pa[tap & 1][2 * c + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bring[(PAR * 9 + tap) & 3][c].x, pa[tap & 1][2 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bring[(PAR * 9 + tap) & 3][c].y, pa[tap & 1][2 * c + 1], acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) bcur[c] = bnext[c];
     }
     __syncthreads();
   };
-  for (int chunk = 0; chunk < nchunks; chunk += 2) {
-    step(areg[0], aok[0], chunk);
-    if (chunk + 1 < nchunks) step(areg[1], aok[1], chunk + 1);
+  for (int chunk = 0; chunk < nchunks; chunk += 4) {
+    step(areg[0], aok[0], chunk, std::integral_constant<int, 0>());
+    if (chunk + 1 < nchunks) step(areg[1], aok[1], chunk + 1, std::integral_constant<int, 1>());
+    if (chunk + 2 < nchunks) step(areg[0], aok[0], chunk + 2, std::integral_constant<int, 2>());
+    if (chunk + 3 < nchunks) step(areg[1], aok[1], chunk + 3, std::integral_constant<int, 3>());
   }
 
   if (has_channels && mout < a.M && co < a.cout_s) {
