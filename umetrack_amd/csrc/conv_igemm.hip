@@ -796,6 +796,11 @@ int launch_conv(const ConvLayer& L, const float* in, int n, int h, int w, const 
     UMT_CHECK_HIP(hipGetLastError());
     return 0;
   }
+  if (L.taps == 1 && L.stride == 1 && !force_gather && M <= 2048 && conv_small_applicable(a, (L.flags & CONV_NO_SMALL) != 0)) {
+    launch_conv_small(a, stream);      // few pixels (the per-frame call's projection and last regressor layer): 16x16x4 tiles
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (L.cout_w % 128 == 0) launch_cfg<2, 2, 2, 2>(a, stream);
   else if (L.cout_w == 96) launch_cfg<UMT_CFG96G>(a, stream);
   else if (L.cout_w == 64) launch_cfg<2, 2, 2, 1>(a, stream);

@@ -18,7 +18,9 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int SM_BM = 16, SM_BN = 64;        // workgroup tile: 16 pixels x 64 output channels (4 waves x 16)
 
-template <bool RES>
+// TAPS = 9: stride-1 3x3; TAPS = 1: stride-1 1x1 (the backbone projection and the regressor's last layer of a per-frame call: no
+// halo, one tap per chunk, bit-identical to conv_igemm_f32)
+template <bool RES, int TAPS>
 __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sA[];   // (16 + 2W + 2) rows x LDA + one zero row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -29,15 +31,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
   const int n0 = has_channels ? n0w : 0;
   const int ks = lane >> 4, lc = lane & 15;                    // k-slot; pixel (B operand) / output channel (A operand) of this lane
   const int W = a.W, H = a.H;
-  const int rows = SM_BM + 2 * W + 2;
-  const int g0 = m0 - W - 1;                                   // global pixel row of LDS row 0
+  const int rows = TAPS == 9 ? SM_BM + 2 * W + 2 : SM_BM;
+  const int g0 = TAPS == 9 ? m0 - W - 1 : m0;                  // global pixel row of LDS row 0
   const int c8_total = a.cin_s >> 3;
   const int nchunks = (a.cin_s + KC - 1) / KC;
   const int perm = (ks & 1) * 4 + (ks >> 1);                   // channel of this k-slot inside an 8-channel group: 0, 4, 1, 5 (then + 2)
 
   // the lane's pixel and the LDS byte address of each of its 9 tap rows (the all-zero row where the neighbour does not exist)
-  int arow[9];
-  {
+  int arow[TAPS];
+  if (TAPS == 9) {
     const int m = m0 + lc;
     const bool live = m < a.M;
     const int mm = live ? m : 0;
@@ -49,8 +51,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
       for (int kx = 0; kx < 3; ++kx) {
         const int yy = y + ky - 1, xx = x + kx - 1;
         const bool ok = live && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        arow[ky * 3 + kx] = ((ok ? lc + ky * W + kx : rows) * LDA + perm) * 4;
+        arow[(ky * 3 + kx) % TAPS] = ((ok ? lc + ky * W + kx : rows) * LDA + perm) * 4;
       }
+  } else {
+    arow[0] = ((m0 + lc < a.M ? lc : rows) * LDA + perm) * 4;
   }
   if (tid < LDA / 4) *reinterpret_cast<float4*>(sA + rows * LDA + 4 * tid) = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -73,9 +77,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
       dst[c] = hi ? make_float2(v.y, v.w) : make_float2(v.x, v.z);
     }
   };
-  load_b(bring[0], 0, 0);
-  load_b(bring[1], 1, 0);
-  load_b(bring[2], 2, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) load_b(bring[i], i % TAPS, min(i / TAPS, nchunks - 1));
 
   // epilogue constants of the lane's four output channels n0 + 4 ks + {0..3}
   const int co = n0 + 4 * ks;
@@ -133,20 +136,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
     };
     read_tap(pa[0], 0);
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-      {   // global tap index T = 9 chunk + tap; slot T % 4 (chunk parity fixed per call of step: PAR)
+    for (int tap = 0; tap < TAPS; ++tap) {
+      {   // global tap index T = TAPS chunk + tap; slot T % 4 (chunk & 3 is fixed per call of step: PAR)
         const int T3 = tap + 3;
-        if (T3 < 9) load_b(bring[(PAR * 9 + T3) & 3], T3, chunk);
-        else load_b(bring[(PAR * 9 + T3) & 3], T3 - 9, min(chunk + 1, nchunks - 1));     // (after the last chunk: a harmless re-read)
+        load_b(bring[(PAR * TAPS + T3) & 3], T3 % TAPS, min(chunk + T3 / TAPS, nchunks - 1));   // (past the last chunk: a harmless re-read)
       }
-      if (tap == 8) load_a(ar, okm, chunk + 2);                 // behind the chunk's last weight load
-      if (tap < 8) read_tap(pa[(tap + 1) & 1], tap + 1);
+      if (tap == TAPS - 1) load_a(ar, okm, chunk + 2);          // behind the chunk's last weight load
+      if (tap + 1 < TAPS) read_tap(pa[(tap + 1) & 1], tap + 1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (chunk * 4 + c >= c8_total) continue;               // zero channel groups past the end (cin_s = 80): skipped, as the halo kernel's one-tile form
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bring[(PAR * 9 + tap) & 3][c].x, pa[tap & 1][2 * c], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bring[(PAR * 9 + tap) & 3][c].y, pa[tap & 1][2 * c + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bring[(PAR * TAPS + tap) & 3][c].x, pa[tap & 1][2 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bring[(PAR * TAPS + tap) & 3][c].y, pa[tap & 1][2 * c + 1], acc, 0, 0, 0);
       }
     }
     __syncthreads();
@@ -176,16 +178,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_small_f32(ConvArgs a) {
 }
 
 bool conv_small_applicable(const ConvArgs& a, bool force_off) {
-  return !force_off && a.taps == 9 && a.stride == 1 && a.W <= 48 && a.cout_w % 32 == 0 && a.cin_s % 8 == 0;
+  return !force_off && (a.taps == 9 || a.taps == 1) && a.stride == 1 && a.W <= 48 && a.cout_w % 32 == 0 && a.cin_s % 8 == 0 &&
+         (a.taps == 9 || !a.residual);
 }
 
 void launch_conv_small(const ConvArgs& a, hipStream_t stream) {
   dim3 grid((a.M + SM_BM - 1) / SM_BM, (a.cout_w + SM_BN - 1) / SM_BN);
-  const size_t lds = (size_t)(SM_BM + 2 * a.W + 2 + 1) * LDA * sizeof(float);
-  if (a.residual)
-    hipLaunchKernelGGL(conv3x3s1_small_f32<true>, grid, dim3(256), lds, stream, a);
+  const int rows = a.taps == 9 ? SM_BM + 2 * a.W + 2 : SM_BM;
+  const size_t lds = (size_t)(rows + 1) * LDA * sizeof(float);
+  if (a.taps == 1)
+    hipLaunchKernelGGL((conv3x3s1_small_f32<false, 1>), grid, dim3(256), lds, stream, a);
+  else if (a.residual)
+    hipLaunchKernelGGL((conv3x3s1_small_f32<true, 9>), grid, dim3(256), lds, stream, a);
   else
-    hipLaunchKernelGGL(conv3x3s1_small_f32<false>, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv3x3s1_small_f32<false, 9>), grid, dim3(256), lds, stream, a);
 }
 
 // ------------------------------------------------------------------------------ stride 2 + down-sample, few pixels
