@@ -229,3 +229,19 @@ def test_hand_model_to_keeps_values_and_sets_kernel_dtypes():
         a, b = getattr(hd, k), torch.as_tensor(getattr(hm, k))
         assert a.dtype == torch.float32 and a.is_contiguous() and torch.equal(a, b.float())
     assert hd.hand_scale == hm.hand_scale or hd.hand_scale is hm.hand_scale
+
+
+def test_tracker_finds_the_frame_behind_its_views():
+    """HandTracker copies a frame into its pinned block in one piece when the views are column blocks of one array
+    (how the reference slices a decoded frame, video_pose_data.py:123-125); anything else takes the per-view copy."""
+    from umetrack_amd.lib.tracker.tracker import _common_parent
+    frames = np.random.default_rng(5).integers(0, 256, size=(3, 48, 256)).astype(np.uint8)
+    mv = frames[1].reshape(48, 4, -1)
+    whole = _common_parent([mv[:, v, :] for v in range(4)])
+    assert whole.shape == (48, 256) and whole.flags["C_CONTIGUOUS"] and np.array_equal(whole, frames[1])
+    part = _common_parent([mv[:, v, :] for v in (2, 1)])                 # any order; rows with a gap: strided block
+    assert part.shape == (48, 128) and part.strides == (256, 1) and np.array_equal(part, frames[1][:, 64:192])
+    assert _common_parent([mv[:, 0, :], mv[:, 3, :]]) is None             # mostly unused columns
+    assert _common_parent([np.zeros((48, 64), np.uint8), np.zeros((48, 64), np.uint8)]) is None      # separate arrays
+    assert _common_parent([mv[:, 0, :], frames[2].reshape(48, 4, -1)[:, 1, :]]) is None               # different rows
+    assert _common_parent([mv[:24, 0, :], mv[:, 1, :]]) is None                                       # different heights

@@ -58,6 +58,31 @@ def _check_view(vi, img):
         raise ValueError(f"view {vi}: expected a 2-D uint8 image, got {img.dtype} {img.shape}")
 
 
+def _common_parent(images):
+    """If the views are column blocks of the same rows of one array (the reference slices a decoded H x 4W frame into its
+    four views, video_pose_data.py:123-125), the 2-D array (H, span) with their common row pitch that covers exactly
+    those columns - contiguous when the views tile whole rows - else None.  Only memory inside the views' common base
+    array is ever addressed."""
+    base = images[0].base
+    if base is None or not isinstance(base, np.ndarray):
+        return None
+    h, pitch = images[0].shape[0], images[0].strides[0]
+    addr = []
+    for img in images:
+        if img.base is not base or img.shape[0] != h or img.strides != (pitch, 1):
+            return None
+        addr.append(img.__array_interface__["data"][0])
+    a0 = min(addr)
+    lo = images[addr.index(a0)]
+    span = max(a + img.shape[1] for a, img in zip(addr, images)) - a0
+    if pitch < span or span * 4 > 5 * sum(img.shape[1] for img in images):      # not one row block, or mostly unused columns
+        return None
+    b_lo, b_hi = np.lib.array_utils.byte_bounds(base) if hasattr(np.lib, "array_utils") else np.byte_bounds(base)
+    if a0 < b_lo or a0 + (h - 1) * pitch + span > b_hi:
+        return None
+    return np.lib.stride_tricks.as_strided(lo, shape=(h, span), strides=(pitch, 1), writeable=False)
+
+
 def _pack_views(views, pairs, device):
     """Upload the source views used by `pairs` [(src view index, crop camera)] once and build the
     per-crop descriptors for umt_warp_crops (the single-image form; HandTracker stages whole frames through
@@ -291,18 +316,31 @@ class HandTracker:
         hands = np.asarray(hands)
         n, bs = len(pairs), len(hands)
         used = sorted({vi for vi, _ in pairs})
-        start, pos = {}, 0
         for vi in used:
-            img = sample.views[vi].image
-            _check_view(vi, img)
-            start[vi] = (pos, img.shape)
-            pos += _align(img.size, 16)
+            _check_view(vi, sample.views[vi].image)
         io = self._io
-        io.plan(n, bs, pos)
-        px = io.host("pixels")
-        for vi in used:
-            p0, shp = start[vi]
-            np.copyto(px[p0:p0 + shp[0] * shp[1]].reshape(shp), sample.views[vi].image)
+        parent = _common_parent([sample.views[vi].image for vi in used])
+        start = {}                                               # view -> (byte offset of its first pixel, row pitch)
+        if parent is not None:
+            # the views are column blocks of one frame (video_pose_data.py:123-125 slices them so): ONE copy of that
+            # frame into the pinned block - a single memcpy when they tile whole rows - instead of a strided copy per view
+            # (1.2 MB: 160 -> 110 us of host time per frame)
+            p_addr = parent.__array_interface__["data"][0]
+            for vi in used:
+                start[vi] = (sample.views[vi].image.__array_interface__["data"][0] - p_addr, parent.shape[1])
+            io.plan(n, bs, _align(parent.size, 16))
+            np.copyto(io.host("pixels")[:parent.size].reshape(parent.shape), parent)
+        else:
+            pos = 0
+            for vi in used:
+                img = sample.views[vi].image
+                start[vi] = (pos, img.shape[1])
+                pos += _align(img.size, 16)
+            io.plan(n, bs, pos)
+            px = io.host("pixels")
+            for vi in used:
+                img = sample.views[vi].image
+                np.copyto(px[start[vi][0]:start[vi][0] + img.size].reshape(img.shape), img)
         io.upload("pixels")
         src, dst, off, pit, K, E = (io.host(k) for k in ("src", "dst", "off", "pitch", "K", "E"))
         c2w = np.stack([crop_cam.camera_to_world_xf for _, crop_cam in pairs]).astype(np.float64, copy=False)
@@ -317,7 +355,7 @@ class HandTracker:
             fx, fy = np.broadcast_to(crop_cam.f, 2)
             dst[k, 0], dst[k, 1], dst[k, 2], dst[k, 3] = fx, fy, crop_cam.c[0], crop_cam.c[1]
             off[k, 0] = start[vi][0]
-            pit[k, 0] = start[vi][1][1]
+            pit[k, 0] = start[vi][1]
             K[k, 0], K[k, 4], K[k, 2], K[k, 5] = fx, fy, crop_cam.c[0], crop_cam.c[1]      # uv_to_window_matrix, camera.py:323-327
         io.host("sr")[:] = np.asarray(ranges)
         io.host("midx")[:, 0] = hands
