@@ -200,6 +200,14 @@ class _FrameIO:
     def host(self, name) -> np.ndarray:
         return self._hv[name]
 
+    def crops(self, n: int, hw) -> torch.Tensor:
+        """The frame's warped crops: a device buffer kept per (n, size) instead of an allocation per frame."""
+        key = (n, int(hw[0]), int(hw[1]))
+        if getattr(self, "_crops_key", None) != key:
+            self._crops = torch.empty(key, dtype=torch.float32, device=self.device)
+            self._crops_key = key
+        return self._crops
+
     def devt(self, name) -> torch.Tensor:
         return self._dv[name]
 
@@ -342,29 +350,31 @@ class HandTracker:
                 img = sample.views[vi].image
                 np.copyto(px[start[vi][0]:start[vi][0] + img.size].reshape(img.shape), img)
         io.upload("pixels")
-        src, dst, off, pit, K, E = (io.host(k) for k in ("src", "dst", "off", "pitch", "K", "E"))
+        hv = io._hv
+        src, dst, K, E = hv["src"], hv["dst"], hv["K"], hv["E"]
         c2w = np.stack([crop_cam.camera_to_world_xf for _, crop_cam in pairs]).astype(np.float64, copy=False)
         w2e = np.linalg.inv(c2w)                                 # tracker.py:213-215, all crops of the frame at once
         w2e[:, :3, 3] *= MM_TO_M
         E[:] = w2e.reshape(n, 16)
         dst[:, 4:] = c2w.reshape(n, 16)
-        K[:] = 0
-        K[:, 8] = 1
+        fc = np.empty((n, 4))                                    # fx, fy, cx, cy of every crop camera
         for k, (vi, crop_cam) in enumerate(pairs):
             src[k] = self._src_row(sample.views[vi].camera)
-            fx, fy = np.broadcast_to(crop_cam.f, 2)
-            dst[k, 0], dst[k, 1], dst[k, 2], dst[k, 3] = fx, fy, crop_cam.c[0], crop_cam.c[1]
-            off[k, 0] = start[vi][0]
-            pit[k, 0] = start[vi][1]
-            K[k, 0], K[k, 4], K[k, 2], K[k, 5] = fx, fy, crop_cam.c[0], crop_cam.c[1]      # uv_to_window_matrix, camera.py:323-327
-        io.host("sr")[:] = np.asarray(ranges)
-        io.host("midx")[:, 0] = hands
-        io.host("hidx")[:, 0] = hands
-        io.host("use")[:, 0] = self._valid_tracking_history[hands]   # enable_memory is stored but unused, as in the reference
-        io.host("status")[:] = 0
+            f = crop_cam.f
+            fc[k] = (f, f, crop_cam.c[0], crop_cam.c[1]) if np.ndim(f) == 0 else (f[0], f[1], crop_cam.c[0], crop_cam.c[1])
+        dst[:, :4] = fc
+        K[:] = 0                                                 # uv_to_window_matrix, camera.py:323-327
+        K[:, 0], K[:, 4], K[:, 2], K[:, 5], K[:, 8] = fc[:, 0], fc[:, 1], fc[:, 2], fc[:, 3], 1
+        hv["off"][:, 0] = [start[vi][0] for vi, _ in pairs]
+        hv["pitch"][:, 0] = [start[vi][1] for vi, _ in pairs]
+        hv["sr"][:] = ranges
+        hv["midx"][:, 0] = hands
+        hv["hidx"][:, 0] = hands
+        hv["use"][:, 0] = self._valid_tracking_history[hands]    # enable_memory is stored but unused, as in the reference
+        hv["status"][:] = 0
         io.upload("params")
         crops = gpu_warp.warp_crops(io.devt("pixels"), io.devt("off"), io.devt("pitch"), io.devt("src"), io.devt("dst"),
-                                    tuple(int(v) for v in self._input_size), self._warp_mode)
+                                    tuple(int(v) for v in self._input_size), self._warp_mode, out=io.crops(n, self._input_size))
         frame_data = InputFrameData(left_images=crops, intrinsics=io.devt("K").view(n, 3, 3),
                                     extrinsics_xf=io.devt("E").view(n, 4, 4))
         frame_desc = InputFrameDesc(sample_range=io.devt("sr"), memory_idx=io.devt("midx").view(bs),
