@@ -327,3 +327,61 @@ def test_bulk_runner_equals_frame_by_frame(hand_model_np):
         assert torch.equal(got.joint_angles[idx.to(dev)].cpu()[keep], ref.joint_angles.cpu()[keep])
         assert (a[:, :3, 3] - orc["wrist_xfs"][keep][:, :3, 3]).abs().max() < 1e-5
         prev_ok = valid[:, t].cpu()
+
+
+@pytest.mark.parametrize("one_kernel", [False, True])
+@pytest.mark.parametrize("head_name,per_row_skel", [("known", False), ("known", True), ("scale", False)])
+def test_head_sequence_equals_stepwise_calls(monkeypatch, one_kernel, head_name, per_row_skel):
+    """umt_head_sequence (temporal module per memory row in one launch + the regressor batched over all T x R rows; with
+    UMT_SEQ_ONEKERNEL the regressor inside that launch, step by step) == T calls of temporal_step + regress_decode,
+    bit for bit: both heads, shared and per-row skeletons, memory switched off for some rows mid-sequence."""
+    from umetrack_amd import _native as nat
+    from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.models.umetrack_model import InputSkeletonData
+    if one_kernel:
+        monkeypatch.setenv("UMT_SEQ_ONEKERNEL", "1")
+    else:
+        monkeypatch.delenv("UMT_SEQ_ONEKERNEL", raising=False)
+    dev = torch.device("cuda", 0)
+    model = model_from_state_dict(arch.make_synthetic_state(21)).to(dev)       # the switch is read per model handle
+    head = nat.HEAD_KNOWN_SKELETON if head_name == "known" else nat.HEAD_PREDICT_SCALE
+    T, R = 5, 7
+    g = torch.Generator().manual_seed(5)
+    fused_t = torch.randn(T, R, 72, 6, 6, generator=g).to(dev)
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(3)
+    cam0 = np.tile(np.eye(4, dtype=np.float32), (T, R, 1, 1))
+    cam0[..., :3, :3] = Rotation.from_rotvec(rng.normal(size=(T * R, 3)) * 0.3).as_matrix().reshape(T, R, 3, 3)
+    cam0[..., :3, 3] = rng.normal(size=(T, R, 3)) * 0.1
+    cam0_t = torch.from_numpy(cam0).to(dev)
+    use_t = torch.ones(T, R, dtype=torch.bool, device=dev)
+    use_t[0] = False
+    use_t[3, ::3] = False
+    hand_rows = (torch.arange(R) % 2).to(dev)
+    skel = None
+    if head == nat.HEAD_KNOWN_SKELETON:
+        hm = load_generic_hand_model()
+        if per_row_skel:
+            hms = [scaled_hand_model(hm, 0.001 * (0.9 + 0.03 * r)) for r in range(R)]
+            skel = InputSkeletonData(torch.stack([h.joint_rotation_axes for h in hms]).to(dev),
+                                     torch.stack([h.joint_rest_positions for h in hms]).to(dev))
+        else:
+            hm_m = scaled_hand_model(hm, 0.001)
+            skel = InputSkeletonData(hm_m.joint_rotation_axes.to(dev), hm_m.joint_rest_positions.to(dev))
+    model.reset_memory()
+    seq = model.head_sequence(head, fused_t, cam0_t, use_t, hand_rows.repeat(T, 1), skel)
+    mem_seq, prev_seq = [x.clone() for x in model.memory_state()]
+    model.reset_memory()
+    midx = torch.arange(R, device=dev)
+    for t in range(T):
+        temporal = model.temporal_step(fused_t[t], cam0_t[t], midx, use_t[t], required_rows=R)
+        out, _ = model.regress_decode(head, temporal, cam0_t[t], hand_rows, skel)
+        assert torch.equal(seq.joint_angles[t], out.joint_angles), t
+        assert torch.equal(seq.wrist_xfs[t], out.wrist_xfs), t
+        assert torch.equal(seq.landmark_uncertainty_sigmas[t], out.landmark_uncertainty_sigmas), t
+        if head == nat.HEAD_PREDICT_SCALE:
+            assert torch.equal(seq.skel_scales[t], out.skel_scales), t
+    mem_step, prev_step = model.memory_state()
+    assert torch.equal(mem_seq, mem_step) and torch.equal(prev_seq, prev_step)
+    model.check_status()

@@ -821,7 +821,8 @@ unsigned conv_flags_from_env() {
       {"UMT_X3_NOS2", CONV_X3_NO_S2},            {"UMT_CONV_NOCHAIN", CONV_NO_CHAIN}, {"UMT_CONV_NOS2P", CONV_NO_S2P},
       {"UMT_CONV_NOPIPE32", CONV_NO_PIPE32},      {"UMT_CONV_NOPIPE64", CONV_NO_PIPE64},
       {"UMT_CONV_NODEPTH", CONV_NO_DEPTH},        {"UMT_CONV_NOSMALL", CONV_NO_SMALL},
-      {"UMT_STEM_VALU", CONV_STEM_VALU},          {"UMT_CONV_NOWALK", CONV_NO_WALK}};
+      {"UMT_STEM_VALU", CONV_STEM_VALU},          {"UMT_CONV_NOWALK", CONV_NO_WALK},
+      {"UMT_SEQ_ONEKERNEL", SEQ_ONE_KERNEL}};
   unsigned f = 0;
   for (const auto& s : kSwitches)
     if (getenv(s.name)) f |= s.bit;

@@ -41,7 +41,9 @@ struct SeqArgs {
   const float* skel;      // (n_skel, 36, 4) skeleton-encoder channels, or null (scale head)
   float* mem;             // handle state (rows, 18, 36)
   float* prev_ext;        // handle state (rows, 16)
-  float* raw_t;           // (T, R, nraw) regressor outputs
+  float* raw_t;           // (T, R, nraw) regressor outputs (one-kernel mode)
+  float* rin;             // (T * R * 36, rin_cs) regressor input rows (split mode: the regressor runs batched afterwards)
+  int rin_cs;             // 80 (known skeleton: channels 72..75 = skeleton, 76..79 zero) or 72 (scale head)
   SeqLayer temp[3], conv[4], out;
   int T, R, n_skel, nraw;
 };
@@ -138,6 +140,11 @@ __device__ __forceinline__ void sq_conv(const SeqLayer& L, const float* __restri
   }
 }
 
+// REGRESS: the regressor layers and the average pool run here too, step by step (the round-2 form, kept as the check
+// and for UMT_SEQ_ONEKERNEL).  Otherwise a step ends after the temporal module: its output rows (+ skeleton channels)
+// go to a.rin and the regressor, which feeds nothing back, runs afterwards over all T x R rows with the batched
+// kernels - nine tenths of a step's matrix work leaves the serial chain.
+template <bool REGRESS>
 __global__ __launch_bounds__(SQ_THREADS) void head_seq_kernel(SeqArgs a) {
   __shared__ __attribute__((aligned(16))) float buf[3][SQ_BUF];
   __shared__ float smem[18 * 36];
@@ -201,18 +208,36 @@ __global__ __launch_bounds__(SQ_THREADS) void head_seq_kernel(SeqArgs a) {
     __syncthreads();
     // channels 0..17 overwrite the memory, 18..89 go on with the skeleton channels behind them (temporal.py:88-89,
     // regressor.py:170-176)
-    for (int i = tid; i < 36 * 96; i += SQ_THREADS) {
-      const int p = i / 96, c = i - p * 96;
-      if (c < 18) {
-        smem[c * 36 + p] = b1[p * SQ_LD + sq_pos(c)];
-      } else if (c < 90) {
-        b0[p * SQ_LD + sq_pos(c - 18)] = b1[p * SQ_LD + sq_pos(c)];
-      } else if (c < 94) {
-        b0[p * SQ_LD + sq_pos(72 + c - 90)] = sskel[p * 4 + (c - 90)];
-      } else {              // channels 76..79 (two threads per pixel write two zeros each)
-        b0[p * SQ_LD + sq_pos(76 + 2 * (c - 94))] = 0.f;
-        b0[p * SQ_LD + sq_pos(77 + 2 * (c - 94))] = 0.f;
+    if (REGRESS) {
+      for (int i = tid; i < 36 * 96; i += SQ_THREADS) {
+        const int p = i / 96, c = i - p * 96;
+        if (c < 18) {
+          smem[c * 36 + p] = b1[p * SQ_LD + sq_pos(c)];
+        } else if (c < 90) {
+          b0[p * SQ_LD + sq_pos(c - 18)] = b1[p * SQ_LD + sq_pos(c)];
+        } else if (c < 94) {
+          b0[p * SQ_LD + sq_pos(72 + c - 90)] = sskel[p * 4 + (c - 90)];
+        } else {              // channels 76..79 (two threads per pixel write two zeros each)
+          b0[p * SQ_LD + sq_pos(76 + 2 * (c - 94))] = 0.f;
+          b0[p * SQ_LD + sq_pos(77 + 2 * (c - 94))] = 0.f;
+        }
       }
+    } else {
+      float* __restrict__ rrow = a.rin + tr * 36 * a.rin_cs;
+      for (int i = tid; i < 36 * 98; i += SQ_THREADS) {
+        const int p = i / 98, c = i - p * 98;
+        if (c < 18) {
+          smem[c * 36 + p] = b1[p * SQ_LD + sq_pos(c)];
+        } else if (c < 90) {
+          rrow[p * a.rin_cs + c - 18] = b1[p * SQ_LD + sq_pos(c)];
+        } else if (c < 94) {
+          if (a.rin_cs == 80) rrow[p * 80 + 72 + c - 90] = sskel[p * 4 + (c - 90)];
+        } else if (a.rin_cs == 80) {
+          rrow[p * 80 + 76 + c - 94] = 0.f;
+        }
+      }
+      __syncthreads();
+      continue;
     }
     __syncthreads();
     sq_conv<9, 80>(a.conv[0], b0, b1, nullptr, wave, lane);
@@ -280,7 +305,7 @@ int64_t head_sequence_workspace_bytes(int T, int R) {
 int launch_head_sequence(const ConvLayer* temp, const ConvLayer* convs, const ConvLayer& out, const SkelParams* skel,
                          const float* skel_axes, const float* skel_rest, int n_skel, const float* fused_t,
                          const float* cam0_t, const uint8_t* use_t, int T, int R, int nraw, float* mem, float* prev_ext,
-                         int32_t* status, float** raw_t, void* workspace, hipStream_t s) {
+                         int32_t* status, float** raw_t, float* rin, int rin_cs, void* workspace, hipStream_t s) {
   // the kernel is instantiated for the network's shapes: temporal 1x1 with 96 padded input channels, regressor 3x3 and
   // the output 1x1 with 80 (76 or 72 channels, both heads)
   for (int i = 0; i < 3; ++i)
@@ -302,12 +327,13 @@ int launch_head_sequence(const ConvLayer* temp, const ConvLayer* convs, const Co
   if (skel) UMT_TRY(launch_skeleton(*skel, skel_axes, skel_rest, n_skel, n_skel == 1 ? 1 : R, skel_rows, 4, 0, s));
   SeqArgs a;
   a.fused_t = fused_t; a.cam0_t = cam0_t; a.rel_t = rel_t; a.use_t = use_eff; a.skel = skel ? skel_rows : nullptr;
-  a.mem = mem; a.prev_ext = prev_ext; a.raw_t = raw;
+  a.mem = mem; a.prev_ext = prev_ext; a.raw_t = raw; a.rin = rin; a.rin_cs = rin_cs;
   for (int i = 0; i < 3; ++i) a.temp[i] = seq_layer(temp[i]);
   for (int i = 0; i < 4; ++i) a.conv[i] = seq_layer(convs[i]);
   a.out = seq_layer(out);
   a.T = T; a.R = R; a.n_skel = n_skel; a.nraw = nraw;
-  hipLaunchKernelGGL(head_seq_kernel, dim3(R), dim3(SQ_THREADS), 0, s, a);
+  if (rin) hipLaunchKernelGGL(head_seq_kernel<false>, dim3(R), dim3(SQ_THREADS), 0, s, a);
+  else hipLaunchKernelGGL(head_seq_kernel<true>, dim3(R), dim3(SQ_THREADS), 0, s, a);
   UMT_CHECK_HIP(hipGetLastError());
   *raw_t = raw;
   return 0;

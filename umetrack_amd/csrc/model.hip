@@ -1156,8 +1156,28 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
   return 0;
 }
 
+// umt_head_sequence's workspace: head_seq.hip's part, the regressor's input rows for all t x rows hands, and the
+// regressor's intermediates for one batch of at most SEQ_REGRESS_BATCH hands
+constexpr int64_t SEQ_REGRESS_BATCH = 8192;
+struct SeqRegressWs {
+  float *rin, *r1, *r2, *r3, *rout;
+};
+static int64_t carve_seq_regress(Carver& cv, int64_t n, SeqRegressWs* w) {
+  const int64_t px = std::min(n, SEQ_REGRESS_BATCH) * 36;
+  w->rin = cv.take<float>(n * 36 * 80);
+  w->r1 = cv.take<float>(px * 80);
+  w->r2 = cv.take<float>(px * 80);
+  w->r3 = cv.take<float>(px * 80);
+  w->rout = cv.take<float>(px * 64);
+  return cv.off;
+}
+
 extern "C" int64_t umt_head_sequence_workspace_bytes(int t, int rows) {
-  return head_sequence_workspace_bytes(t > 0 ? t : 1, rows > 0 ? rows : 1);
+  t = t > 0 ? t : 1;
+  rows = rows > 0 ? rows : 1;
+  Carver cv(nullptr, 0);
+  SeqRegressWs w;
+  return round_up64(head_sequence_workspace_bytes(t, rows), 256) + carve_seq_regress(cv, (int64_t)t * rows, &w);
 }
 
 extern "C" int umt_head_sequence(umt_model* m, int head, const float* fused_t, const float* cam0_t,
@@ -1185,8 +1205,33 @@ extern "C" int umt_head_sequence(umt_model* m, int head, const float* fused_t, c
   const ConvLayer convs[4] = {B[0].conv1, B[0].conv2, B[1].conv1, B[1].conv2};
   const int nraw = known ? 62 : 63;
   float* raw = nullptr;
-  UMT_TRY(launch_head_sequence(m->temp, convs, m->reg_out[head], known ? &m->skel : nullptr, skel_axes, skel_rest, n_skel,
-                               fused_t, cam0_t, use_memory_t, t, rows, nraw, m->mem, m->prev_ext, m->status, &raw, workspace, s));
+  const int64_t n = (int64_t)t * rows;
+  if (m->conv_flags & SEQ_ONE_KERNEL) {
+    UMT_TRY(launch_head_sequence(m->temp, convs, m->reg_out[head], known ? &m->skel : nullptr, skel_axes, skel_rest, n_skel,
+                                 fused_t, cam0_t, use_memory_t, t, rows, nraw, m->mem, m->prev_ext, m->status, &raw, nullptr, 0,
+                                 workspace, s));
+  } else {
+    // the serial part (temporal module, one workgroup per memory row) leaves the regressor's input rows behind; the
+    // regressor, which feeds nothing back, then runs over all t x rows hands with the batched kernels
+    const int64_t seq_bytes = round_up64(head_sequence_workspace_bytes(t, rows), 256);
+    Carver cv((char*)workspace + seq_bytes, workspace_bytes - seq_bytes);
+    SeqRegressWs w;
+    carve_seq_regress(cv, n, &w);
+    const int cs = known ? 80 : 72;
+    UMT_TRY(launch_head_sequence(m->temp, convs, m->reg_out[head], known ? &m->skel : nullptr, skel_axes, skel_rest, n_skel,
+                                 fused_t, cam0_t, use_memory_t, t, rows, nraw, m->mem, m->prev_ext, m->status, &raw, w.rin, cs,
+                                 workspace, s));
+    for (int64_t b0 = 0; b0 < n; b0 += SEQ_REGRESS_BATCH) {
+      const int bs = (int)std::min(SEQ_REGRESS_BATCH, n - b0);
+      const float* rin = w.rin + b0 * 36 * cs;
+      UMT_TRY(launch_conv(convs[0], rin, bs, 6, 6, nullptr, w.r1, s));
+      UMT_TRY(launch_conv(convs[1], w.r1, bs, 6, 6, rin, w.r2, s));
+      UMT_TRY(launch_conv(convs[2], w.r2, bs, 6, 6, nullptr, w.r1, s));
+      UMT_TRY(launch_conv(convs[3], w.r1, bs, 6, 6, w.r2, w.r3, s));
+      UMT_TRY(launch_conv(m->reg_out[head], w.r3, bs, 6, 6, nullptr, w.rout, s));
+      UMT_TRY(launch_avgpool(w.rout, 64, nraw, bs, raw + b0 * nraw, s));
+    }
+  }
   // Procrustes decode + wrist recovery for all t x rows outputs at once (hand_idx is time-major like the outputs)
   UMT_TRY(launch_decode(raw, nraw, !known, cam0_t, hand_idx, t * rows, joint_angles_t, wrist_xfs_t, sigmas_t, skel_scales_t,
                         m->status, s));

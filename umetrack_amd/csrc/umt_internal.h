@@ -67,6 +67,7 @@ enum : unsigned {
   CONV_NO_SMALL = 8192u,    // UMT_CONV_NOSMALL: few-pixel fp32 launches on conv3x3s1_halo_f32<4,1,1,1> instead of conv_small.hip
   CONV_STEM_VALU = 16384u,  // UMT_STEM_VALU: the stem on the vector pipe (stem_kernel) instead of stem_mfma_kernel
   CONV_NO_WALK = 32768u,    // UMT_CONV_NOWALK: bf16 fused stride-2 layers one tile per workgroup instead of conv3x3s2_walk_bf16
+  SEQ_ONE_KERNEL = 65536u,  // UMT_SEQ_ONEKERNEL: umt_head_sequence runs the regressor inside head_seq_kernel, step by step
 };
 unsigned conv_flags_from_env();
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -215,11 +216,13 @@ int launch_gather_cam0(const float* extrinsics, const int64_t* sample_range, int
 
 // head_seq.hip: temporal module + regressor layers + average pool for R memory rows x T steps in one launch.
 // temp: 3 temporal layers, convs: conv1, conv2 of the two regressor blocks, out: the 1x1 output layer; skel null for the
-// scale head.  *raw_t receives the (T, R, nraw) regressor outputs inside `workspace`.
+// scale head.  *raw_t receives the (T, R, nraw) buffer inside `workspace`: filled by the kernel when rin is null (one-kernel
+// mode); with rin the kernel stops after the temporal module and writes the regressor's input rows (T * R * 36, rin_cs)
+// for the caller to run the batched regressor into *raw_t.
 int64_t head_sequence_workspace_bytes(int T, int R);
 int launch_head_sequence(const ConvLayer* temp, const ConvLayer* convs, const ConvLayer& out, const SkelParams* skel,
                          const float* skel_axes, const float* skel_rest, int n_skel, const float* fused_t,
                          const float* cam0_t, const uint8_t* use_t, int T, int R, int nraw, float* mem, float* prev_ext,
-                         int32_t* status, float** raw_t, void* workspace, hipStream_t s);
+                         int32_t* status, float** raw_t, float* rin, int rin_cs, void* workspace, hipStream_t s);
 
 }  // namespace umt
