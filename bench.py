@@ -552,7 +552,8 @@ def main():
                        "dense peak / 6; 2 timed steps")
         bf16_side = side_mode("bf16", BF16_MATRIX_PEAK_TFLOPS,
                               "UMT_PREC_BF16: bf16 backbone activations and weights, fp32 accumulation; fusion, temporal memory, "
-                              "head and FK stay fp32; peak = bf16 dense matrix peak; 2 timed steps; the difference from the fp32 "
+                              "head and FK stay fp32 tensors (the head's 3x3 layers on the split-operand kernels of the fp32x3 mode for batches "
+                              "of 228 hands or more: fp32-rounding-level accuracy); peak = bf16 dense matrix peak; 2 timed steps; the difference from the fp32 "
                               "mode depends on the weights: `stated_tolerance_mm` is 1.5 x the worst of 8 weight seeds on this "
                               "batch (profiles/r03_bf16_tolerance_8seeds.json, tools/bf16_tolerance.py; held by "
                               "tests/test_gpu_bf16.py); this run's weight seed is 0")

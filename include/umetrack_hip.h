@@ -44,7 +44,10 @@ enum {
  * UMT_PREC_BF16: bf16 backbone activations and weights, fp32 accumulation (reported separately).
  * UMT_PREC_FP32_BF16X3: every tensor stays fp32; inside the stride-1 3x3 backbone layers each fp32 operand is
  *   the exact sum of three bf16 pieces and a product is six bf16 matrix instructions accumulated in fp32
- *   (the dropped cross terms are <= 2^-23 of the product).  fp32-level accuracy, not bit-identical to FP32. */
+ *   (the dropped cross terms are <= 2^-23 of the product).  fp32-level accuracy, not bit-identical to FP32.
+ * In both non-FP32 modes umt_model_forward also runs the known-skeleton regressor's 3x3 layers that way when bs >= 228
+ * (8192 head pixels: the batches the wide tiles are for); the stage entry points (umt_regress_decode, umt_head_sequence)
+ * take no precision and always use the FP32 kernels. */
 enum { UMT_PREC_FP32 = 0, UMT_PREC_BF16 = 1, UMT_PREC_FP32_BF16X3 = 2 };
 enum { UMT_HEAD_KNOWN_SKELETON = 0, UMT_HEAD_PREDICT_SCALE = 1 };
 enum { UMT_WARP_CV2_FIXED_POINT = 0, UMT_WARP_FLOAT = 1, UMT_WARP_CV2_FIXED_POINT_F64 = 2 };

@@ -117,3 +117,52 @@ def test_x3_random_batch_within_a_hundredth_of_a_millimetre_of_the_oracle():
         e_lm = np.abs(lm_got - lm_want).max()          # millimetres
         print(f"step {step}: wrist {e_t * 1e3:.5f} mm, angles {e_a:.2e} rad, landmarks {e_lm:.5f} mm")
         assert e_t < 1e-5 and e_a < 2e-5 and e_lm < 0.01
+
+
+@pytest.mark.parametrize("head_name", ["known", "scale"])
+def test_x3_head_layers_on_large_batches_stay_at_fp32_rounding(monkeypatch, head_name):
+    """From 8192 head pixels on (228 hands) the bf16 / fp32x3 modes of umt_model_forward run the known-skeleton regressor's
+    3x3 layers on the split-operand kernels too (UMT_HEAD_NOX3 keeps them on the fp32 kernels; the scale head's 72-channel
+    rows are not a multiple of the kernels' 16-channel groups and always stay on the fp32 kernels).  256 hands: same
+    backbone bits, so every difference is the head's - it must be there for the known-skeleton head (the switch works),
+    absent for the scale head, and both stay within the fp32 parity mode's own tolerances against the CPU oracle."""
+    from umetrack_amd.lib.common.hand import load_generic_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.models.umetrack_model import InputFrameData, InputFrameDesc, InputSkeletonData
+    from scipy.spatial.transform import Rotation
+    state = arch.make_synthetic_state(41)
+    monkeypatch.delenv("UMT_HEAD_NOX3", raising=False)
+    split = model_from_state_dict(state).to("cuda")
+    monkeypatch.setenv("UMT_HEAD_NOX3", "1")
+    plain = model_from_state_dict(state).to("cuda")        # the switch is read per model handle
+    split.precision = plain.precision = "fp32x3"
+    rng = np.random.default_rng(8)
+    bs = 256
+    hm = load_generic_hand_model()
+    skel = InputSkeletonData(hm.joint_rotation_axes, hm.joint_rest_positions * 0.001)
+    img = torch.from_numpy(rng.integers(0, 256, size=(2 * bs, 96, 96)).astype(np.float32) / np.float32(255))
+    K = torch.zeros(2 * bs, 3, 3)
+    K[:, 0, 0] = K[:, 1, 1] = torch.from_numpy(rng.uniform(150, 400, 2 * bs).astype(np.float32))
+    K[:, 0, 2] = K[:, 1, 2] = 47.5
+    K[:, 2, 2] = 1
+    E = np.tile(np.eye(4, dtype=np.float32), (2 * bs, 1, 1))
+    E[:, :3, :3] = Rotation.from_rotvec(rng.normal(size=(2 * bs, 3)) * 0.5).as_matrix()
+    E[:, :3, 3] = rng.normal(size=(2 * bs, 3)) * 0.2
+    fd = InputFrameData(img, K, torch.from_numpy(E))
+    desc = InputFrameDesc(torch.arange(bs)[:, None] * 2 + torch.tensor([0, 2]), torch.arange(bs),
+                          torch.zeros(bs, dtype=torch.bool), torch.arange(bs) % 2)
+    o32 = om.OracleModel(state, torch.float32)
+    if head_name == "known":
+        a, b = split.regress_pose_use_skeleton(fd, desc, skel), plain.regress_pose_use_skeleton(fd, desc, skel)
+        with torch.no_grad():
+            want = o32.regress_pose_use_skeleton(fd, desc, skel)
+    else:
+        a, b = split.regress_pose_pred_skel_scale(fd, desc), plain.regress_pose_pred_skel_scale(fd, desc)
+        with torch.no_grad():
+            want = o32.regress_pose_pred_skel_scale(fd, desc)
+    assert torch.equal(a.joint_angles, b.joint_angles) == (head_name == "scale"), "which kernels ran the head's 3x3 layers"
+    for got in (a, b):
+        e_t = np.abs(got.wrist_xfs.cpu().numpy()[:, :3, 3] - want["wrist_xfs"].numpy()[:, :3, 3]).max()
+        e_a = np.abs(got.joint_angles.cpu().numpy() - want["joint_angles"].numpy()).max()
+        assert e_t < 1e-5 and e_a < 2e-5, (e_t, e_a)
+    split.check_status()

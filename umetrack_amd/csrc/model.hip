@@ -689,9 +689,13 @@ static int temporal_rows(umt_model* m, const float* cam0, const int64_t* midx, c
 }
 
 // rin (channels 0..71 set; head k: 72..75 filled here) -> decoded outputs
+// x3: the four 3x3 layers on the split-operand kernels (conv_x3.hip) when the batch is large enough for the wide tiles -
+// the bf16 and fp32x3 modes of umt_model_forward, whose results are not tied bit for bit to the fp32 kernels'; fp32
+// tensors and fp32-rounding-level accuracy either way (tests/test_gpu_x3.py)
 static int regress_rows(umt_model* m, int head, const float* skel_axes, const float* skel_rest, int n_skel,
                         const float* cam0, const int64_t* hand_idx, int bs, const HeadWs& w, float* joint_angles,
-                        float* wrist_xfs, float* sigmas, float* skel_scales, float* raw_out, hipStream_t s) {
+                        float* wrist_xfs, float* sigmas, float* skel_scales, float* raw_out, hipStream_t s,
+                        bool x3 = false) {
   const int cs = head == UMT_HEAD_KNOWN_SKELETON ? 80 : 72;
   const int nraw = head == UMT_HEAD_KNOWN_SKELETON ? 62 : 63;
   if (head == UMT_HEAD_KNOWN_SKELETON) {
@@ -700,10 +704,11 @@ static int regress_rows(umt_model* m, int head, const float* skel_axes, const fl
     UMT_TRY(launch_skeleton(m->skel, skel_axes, skel_rest, n_skel, bs, w.rin, cs, 72, s));
   }
   const BlockLayers* B = m->reg_blocks[head];
-  UMT_TRY(launch_conv(B[0].conv1, w.rin, bs, 6, 6, nullptr, w.r1, s));
-  UMT_TRY(launch_conv(B[0].conv2, w.r1, bs, 6, 6, w.rin, w.r2, s));
-  UMT_TRY(launch_conv(B[1].conv1, w.r2, bs, 6, 6, nullptr, w.r1, s));
-  UMT_TRY(launch_conv(B[1].conv2, w.r1, bs, 6, 6, w.r2, w.r3, s));
+  x3 = x3 && !(m->conv_flags & HEAD_NO_X3) && (int64_t)bs * 36 >= HEAD_X3_MIN_PIXELS;
+  UMT_TRY(conv_f32(B[0].conv1, x3, w.rin, bs, 6, nullptr, w.r1, s));
+  UMT_TRY(conv_f32(B[0].conv2, x3, w.r1, bs, 6, w.rin, w.r2, s));
+  UMT_TRY(conv_f32(B[1].conv1, x3, w.r2, bs, 6, nullptr, w.r1, s));
+  UMT_TRY(conv_f32(B[1].conv2, x3, w.r1, bs, 6, w.r2, w.r3, s));
   UMT_TRY(launch_conv(m->reg_out[head], w.r3, bs, 6, 6, nullptr, w.rout, s));
   UMT_TRY(launch_avgpool(w.rout, 64, nraw, bs, w.raw, s));
   if (raw_out) UMT_CHECK_HIP(hipMemcpyAsync(raw_out, w.raw, (size_t)bs * nraw * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -882,6 +887,13 @@ static int finalize_on_device(umt_model* m, int device) {
     }
     pack_conv(m, host, packed, &m->reg_out[h], p + ".2.weight", p + ".2.bias", "", 1, 0);
     pack_conv_seq(m, host, packed_seq, &m->reg_out[h], p + ".2.weight");
+    // split-operand copies for the non-fp32 modes' large batches (regress_rows)
+    for (int b = 0; b < 2; ++b) {
+      const std::string pb = p + "." + std::to_string(b);
+      BlockLayers& B = m->reg_blocks[h][b];
+      if (B.conv1.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.conv1, pb + ".conv1.weight");
+      if (B.conv2.cin_s % 16 == 0) pack_conv_x3(m, host_h, packed_x3, &B.conv2, pb + ".conv2.weight");
+    }
   }
   // skeleton encoder
   size_t sk_off[4];
@@ -1151,7 +1163,7 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
   UMT_CHECK_HIP(hipMemsetAsync(hw.rin, 0, (size_t)bs * 36 * 80 * sizeof(float), s));
   UMT_TRY(temporal_rows(m, hw.cam0, memory_idx, use_memory, bs, hw, hw.rin, cs, s));
   UMT_TRY(regress_rows(m, head, skel_axes, skel_rest, n_skel, hw.cam0, hand_idx, bs, hw, joint_angles, wrist_xfs, sigmas,
-                       skel_scales, nullptr, s));
+                       skel_scales, nullptr, s, precision != UMT_PREC_FP32));
   if (ev) UMT_CHECK_HIP(hipEventRecord(ev[2], s));
   return 0;
 }

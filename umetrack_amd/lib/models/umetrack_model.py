@@ -127,7 +127,9 @@ class UmeTrackModel:
         """"fp32" (default, the reference's arithmetic), "bf16" (bf16 backbone activations and
         weights with fp32 accumulation; fusion, temporal memory and the head stay fp32) or "fp32x3"
         (fp32 tensors; the stride-1 3x3 backbone layers multiply three-way bf16 splits of their fp32
-        operands on the bf16 matrix pipe - fp32-level accuracy, not bit-identical to "fp32")."""
+        operands on the bf16 matrix pipe - fp32-level accuracy, not bit-identical to "fp32").  In both non-fp32 modes the
+        known-skeleton regressor's 3x3 layers run on those split-operand kernels too when a forward call has 228 hands or
+        more (UMT_HEAD_NOX3 turns that off)."""
         return _PRECISIONS_INV[self._precision]
 
     @precision.setter
