@@ -57,7 +57,7 @@ enum { UMT_WARP_NO_DEPTH_CHECK = 0x100 };
 
 const char* umt_last_error(void);
 /* bumped on every signature change; bindings compare it with the value they were written for */
-#define UMT_ABI_VERSION 3
+#define UMT_ABI_VERSION 4
 int umt_abi_version(void);
 
 /* Conditions a kernel can detect but an asynchronous call cannot return: the kernels OR these bits into a status
@@ -152,6 +152,12 @@ int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offset, const i
  * out dev f32 (n,out_h,out_w) (not divided by 255, as in the reference)                           */
 int umt_resample_pinhole(const float* images, const float* xfs, int n, int h, int w, int out_h,
                          int out_w, float* out, void* stream);
+
+/* ---- the first layer group of A3 alone: Conv2d(1,32,3,pad 1) -> BatchNorm2d -> ReLU -> MaxPool2d(2,2),
+ * lib/models/model_utils.py:119-124.  images dev f32 (n,96,96) -> out dev (n,48,48,32) channels-last: float for
+ * UMT_PREC_FP32 and UMT_PREC_FP32_BF16X3, bf16 (uint16_t) for UMT_PREC_BF16 - the tensor the rest of the backbone
+ * reads in that mode.  For the tests that hold the bf16 mode's split-operand stem against the fp32 one.       */
+int umt_stem_forward(umt_model* m, const float* images, int n, int precision, void* out, void* stream);
 
 /* ---- A3: _image_backbone, lib/models/umetrack_model.py:127-129, model_utils.py:107-138 ----
  * images dev f32 (n,96,96) -> features dev f32 (n,72,6,6)                                          */

@@ -325,11 +325,12 @@ def test_fp32_few_pixel_kernel_bit_identical_to_halo_kernel(tmp_path):
 
 
 @pytest.mark.gpu
-def test_matrix_pipe_stem_bit_identical_to_vector_stem(tmp_path):
+def test_matrix_pipe_stem_bit_identical_to_vector_stem(tmp_path, monkeypatch):
     """The stem (conv 1 -> 32 + BN + ReLU + max-pool) runs on v_mfma_f32_32x32x2_f32 (stem_mfma_kernel: K = 9 padded to 10,
     max-pool by DPP inside the accumulator quads); with UMT_STEM_VALU=1 (read once per process, hence the child process)
     on the vector pipe.  The matrix instruction is the same k-ordered fmaf chain, so fp32 and bf16 backbone features must
-    agree bit for bit, and a NaN / inf pixel must poison exactly the same pooled pixels."""
+    agree bit for bit, and a NaN / inf pixel must poison exactly the same pooled pixels.  (The bf16 mode's default stem
+    multiplies split operands on the bf16 matrix instructions instead - next test; UMT_STEM_NOSPLIT keeps the chain.)"""
     import os
     import subprocess
     import sys
@@ -352,6 +353,7 @@ def test_matrix_pipe_stem_bit_identical_to_vector_stem(tmp_path):
         f"np.save({str(out)!r}, np.concatenate(res))\n")
     subprocess.run([sys.executable, "-c", body], check=True, env=dict(os.environ, UMT_STEM_VALU="1"), timeout=110)
     from umetrack_amd import arch
+    monkeypatch.setenv("UMT_STEM_NOSPLIT", "1")            # read per model handle
     gm = model_from_state_dict(arch.make_synthetic_state(4)).to("cuda")
     img = torch.rand(1030, 96, 96, generator=torch.Generator().manual_seed(78))
     img[3, 0, 0] = float("nan")
@@ -365,3 +367,39 @@ def test_matrix_pipe_stem_bit_identical_to_vector_stem(tmp_path):
     got, want = np.concatenate(res), np.load(out)
     assert np.isnan(got).any() and np.isfinite(got[:2]).all()
     assert np.array_equal(got, want, equal_nan=True), float(np.nanmax(np.abs(got - want)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3, 1030])
+def test_bf16_stem_on_split_operands_equals_the_rounded_fp32_stem(monkeypatch, n):
+    """The bf16 mode's stem (umt_stem_forward, UMT_PREC_BF16) multiplies (hi, lo) bf16 pairs of pixels and weights on
+    v_mfma_f32_32x32x16_bf16 and drops the lo x lo term: 2^-16 of a product, against the 2^-9 rounding of the stored bf16
+    output.  So it must equal the bf16 rounding of the fp32 stem except where the fp32 value sits within that distance of a
+    rounding boundary (0.13 % of the outputs) and stay within half a bf16 step of the fp32 value everywhere; NaN / inf
+    pixels poison the same pooled pixels; and UMT_STEM_NOSPLIT gives the rounded fp32 stem exactly."""
+    import torch
+    from umetrack_amd import arch
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    monkeypatch.delenv("UMT_STEM_NOSPLIT", raising=False)
+    gm = model_from_state_dict(arch.make_synthetic_state(4)).to("cuda")
+    monkeypatch.setenv("UMT_STEM_NOSPLIT", "1")
+    chain = model_from_state_dict(arch.make_synthetic_state(4)).to("cuda")
+    img = torch.rand(n, 96, 96, generator=torch.Generator().manual_seed(80))
+    img[1, 0, 0] = float("nan")
+    img[2, 95, 95] = float("inf")
+    img[n - 1, 40, 41] = float("nan")
+    ref = gm.stem(img)                                    # fp32 mode
+    assert ref.dtype == torch.float32 and tuple(ref.shape) == (n, 48, 48, 32)
+    gm.precision = chain.precision = "bf16"
+    got, rounded = gm.stem(img), chain.stem(img)
+    assert got.dtype == torch.bfloat16
+    want = ref.to(torch.bfloat16)
+    assert torch.equal(rounded.view(torch.int16), want.view(torch.int16))
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.isnan(got).any()
+    ok = ~torch.isnan(want)
+    g, w, r = got[ok].float(), want[ok].float(), ref[ok]
+    frac = (g != w).float().mean().item()
+    assert frac < 0.005, frac                             # measured 0.0013
+    # within half a bf16 step of the fp32 value, plus the dropped term and the fp32 summation order: 2^-16 of the largest
+    # output (measured 2^-17.5; relative to the value itself it is unbounded where the nine products cancel)
+    assert ((g - r).abs() <= r.abs() * 2.0 ** -8 + r.abs().max() * 2.0 ** -16).all()

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(handle, n), f"{n} declared in include/umetrack_hip.h but not exported"
     assert sorted(nat.SIGNATURES) == names, "ctypes table and header disagree"
-    assert nat.lib().umt_abi_version() == nat.ABI_VERSION == 3
+    assert nat.lib().umt_abi_version() == nat.ABI_VERSION == 4
 
 
 def test_native_key_table_equals_python_spec():

@@ -18,7 +18,7 @@ HEAD_KNOWN_SKELETON, HEAD_PREDICT_SCALE = 0, 1
 WARP_CV2_FIXED_POINT, WARP_FLOAT, WARP_CV2_FIXED_POINT_F64 = 0, 1, 2
 WARP_NO_DEPTH_CHECK = 0x100
 METRIC_WORDS = 108
-ABI_VERSION = 3          # UMT_ABI_VERSION of include/umetrack_hip.h these signatures were written for
+ABI_VERSION = 4          # UMT_ABI_VERSION of include/umetrack_hip.h these signatures were written for
 STATUS_BITS = {1: "use_memory on a memory row whose previous extrinsics are singular (torch.inverse raises in the "
                   "reference, temporal.py:66); the sample ran as use_memory=False",
                2: "memory_idx outside the reserved memory rows",
@@ -58,6 +58,7 @@ SIGNATURES = {
                                  c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "umt_warp_crops": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     "umt_resample_pinhole": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "umt_stem_forward": (c_int, [_P, _P, c_int, c_int, _P, _P]),
     "umt_backbone_forward": (c_int, [_P, _P, c_int, c_int, _P, _P, c_int64, _P]),
     "umt_fuse_views": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P, _P, c_int64, _P]),
     "umt_temporal_step": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int64, _P]),

@@ -822,7 +822,8 @@ unsigned conv_flags_from_env() {
       {"UMT_CONV_NOPIPE32", CONV_NO_PIPE32},      {"UMT_CONV_NOPIPE64", CONV_NO_PIPE64},
       {"UMT_CONV_NODEPTH", CONV_NO_DEPTH},        {"UMT_CONV_NOSMALL", CONV_NO_SMALL},
       {"UMT_STEM_VALU", CONV_STEM_VALU},          {"UMT_CONV_NOWALK", CONV_NO_WALK},
-      {"UMT_SEQ_ONEKERNEL", SEQ_ONE_KERNEL},      {"UMT_HEAD_NOX3", HEAD_NO_X3}};
+      {"UMT_SEQ_ONEKERNEL", SEQ_ONE_KERNEL},      {"UMT_HEAD_NOX3", HEAD_NO_X3},
+      {"UMT_STEM_NOSPLIT", STEM_NO_SPLIT}};
   unsigned f = 0;
   for (const auto& s : kSwitches)
     if (getenv(s.name)) f |= s.bit;

@@ -935,7 +935,7 @@ static int finalize_on_device(umt_model* m, int device) {
   for (const PackedH& p : packed_h) p.layer->wh = m->slab_h + p.off;   // every size is a multiple of 8 bf16 = 16 B
   for (const PackedH& p : packed_x3) p.layer->wx3 = m->slab_h + p.off;
   m->stem = StemParams{m->slab + stem_off[0], m->slab + stem_off[1], m->slab + stem_off[2], m->slab + stem_off[3],
-                       (m->conv_flags & CONV_STEM_VALU) ? 1 : 0};
+                       (m->conv_flags & CONV_STEM_VALU) ? 1 : (m->conv_flags & STEM_NO_SPLIT) ? 2 : 0};
   m->skel = SkelParams{m->slab + sk_off[0], m->slab + sk_off[1], m->slab + sk_off[2], m->slab + sk_off[3]};
   m->status = reinterpret_cast<int32_t*>(m->slab + status_off);
   return 0;
@@ -1056,6 +1056,14 @@ static int check_ws(const char* what, void* ws, int64_t have, int64_t need) {
   UMT_REQUIRE(have >= need, UMT_ERR_WORKSPACE, "%s: workspace has %lld bytes, needs %lld", what, (long long)have,
               (long long)need);
   return 0;
+}
+
+extern "C" int umt_stem_forward(umt_model* m, const float* images, int n, int precision, void* out, void* stream) {
+  UMT_TRY(check_ready(m));
+  UMT_REQUIRE(precision >= UMT_PREC_FP32 && precision <= UMT_PREC_FP32_BF16X3, UMT_ERR_INVALID, "stem: precision = %d", precision);
+  UMT_REQUIRE(n > 0 && images && out, UMT_ERR_INVALID, "stem: n=%d or null pointer", n);
+  if (precision == UMT_PREC_BF16) return launch_stem_bf16(m->stem, images, n, (uint16_t*)out, (hipStream_t)stream);
+  return launch_stem(m->stem, images, n, (float*)out, (hipStream_t)stream);
 }
 
 extern "C" int umt_backbone_forward(umt_model* m, const float* images, int n, int precision, float* features,

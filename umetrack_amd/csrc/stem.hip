@@ -162,10 +162,30 @@ __device__ __forceinline__ void stem_pair_max8(float& a, float& b, float& c, flo
 // no wave waits on HBM between bands; the constants are forced resident before the loop because the compiler's wait-count
 // pass otherwise carries their pending loads into the loop as vmcnt waits that drain every band's prefetch and stores.
 // Few-crop launches (the tracker's per-frame call) keep one band per workgroup for the parallelism.
-template <bool OUT_BF16>
+//
+// SPLIT (the bf16 mode's stem): the same sums on v_mfma_f32_32x32x16_bf16.  A staged pixel is the pair (hi, lo) of bf16
+// numbers with hi = bf16(v), lo = bf16(v - hi) in one dword, a weight likewise, and a tile is three instructions
+// w_lo . p_hi + w_hi . p_lo + w_hi . p_hi (K = 16 slots: taps 0..7 on the lower half-wave, tap 8 and seven zeros on the
+// upper) instead of five of twice the length: 96 cycles of matrix pipe per tile instead of 320.  The dropped w_lo . p_lo
+// is 2^-16 of a product, far below the bf16 rounding of the stored output (2^-9): not bit-identical to the fp32 chain,
+// equal to it after that rounding for all but about one output in 10^4 (tests/test_gpu_edges.py states the bound).
+constexpr int STEM_ZTAIL = 168;      // zero floats behind a staged band: the upper half-wave's seven unused k slots read them
+
+__device__ __forceinline__ void stem_split2(float a, float b, unsigned& pa, unsigned& pb) {
+  typedef __bf16 stem_bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float stem_f32x2v __attribute__((ext_vector_type(2)));
+  const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((stem_f32x2v){a, b}, stem_bf16x2));
+  const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);   // exact
+  const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector((stem_f32x2v){ra, rb}, stem_bf16x2));
+  pa = (h << 16) | (l & 0xffffu);
+  pb = (h & 0xffff0000u) | (l >> 16);
+}
+
+template <bool OUT_BF16, bool SPLIT>
 __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const float* __restrict__ images, int n, int nb,
                                                         void* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) float sbuf[2][STEM_IN_ROWS * STEM_LDW];
+  constexpr int SBUF = STEM_IN_ROWS * STEM_LDW + (SPLIT ? STEM_ZTAIL : 0);
+  __shared__ __attribute__((aligned(16))) float sbuf[2][SBUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int per_img = (48 / STEM_ROWS) / nb;
@@ -184,16 +204,27 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const floa
   };
   auto stage = [&](float* dstbuf, float4 v, bool ok) -> int {
     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nonfinite = !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    if (SPLIT) {          // (hi, lo) pairs; a non-finite pixel keeps its exponent bits in hi, which is what the check reads
+      unsigned q0, q1, q2, q3;
+      stem_split2(v.x, v.y, q0, q1);
+      stem_split2(v.z, v.w, q2, q3);
+      v = make_float4(__builtin_bit_cast(float, q0), __builtin_bit_cast(float, q1), __builtin_bit_cast(float, q2),
+                      __builtin_bit_cast(float, q3));
+    }
     if (stager) {
       float* d = dstbuf + sr * STEM_LDW + 2 + 4 * sc4;
       *reinterpret_cast<float2*>(d) = make_float2(v.x, v.y);
       *reinterpret_cast<float2*>(d + 2) = make_float2(v.z, v.w);
     }
-    return !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    return nonfinite;
   };
   if (tid < 2 * STEM_IN_ROWS) {
-    float* d = &sbuf[0][0] + tid * STEM_LDW;                  // both buffers: the two zero columns either side of a row
+    float* d = &sbuf[tid / STEM_IN_ROWS][(tid % STEM_IN_ROWS) * STEM_LDW];   // both buffers: the two zero columns either side of a row
     d[0] = d[1] = d[98] = d[99] = 0.f;
+  }
+  if (SPLIT) {
+    for (int i = tid; i < 2 * STEM_ZTAIL; i += 256) sbuf[i / STEM_ZTAIL][STEM_IN_ROWS * STEM_LDW + i % STEM_ZTAIL] = 0.f;
   }
   int bad = stage(sbuf[0], fetch(band0), row_ok(band0));
   // weights of this lane's channel li for the taps 2j + lh (the tenth slot: 0), BN constants of its 16 channels
@@ -214,6 +245,27 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const floa
   for (int j = 0; j < 5; ++j) {
     const int tap = 2 * j + lh, ky = tap / 3, kx = tap - 3 * ky;
     toff[j] = tap < 9 ? ky * STEM_LDW + li + kx + 1 : -1;
+  }
+  // SPLIT: k slot s of the lane's half-wave is tap s (lower half) or tap 8 then nothing (upper half); the packed weight
+  // pairs of the lane's channel li and the float index of each slot's pixel from the buffer base (tile a, column block 0)
+  unsigned wh[4] = {0, 0, 0, 0}, wl[4] = {0, 0, 0, 0};
+  int poff[8];
+  if (SPLIT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t0 = lh ? (i == 0 ? 8 : -1) : 2 * i, t1 = lh ? -1 : 2 * i + 1;
+      const float w0 = t0 >= 0 ? p.w[(t0 < 0 ? 0 : t0) * 32 + li] : 0.f, w1 = t1 >= 0 ? p.w[(t1 < 0 ? 0 : t1) * 32 + li] : 0.f;
+      unsigned q0, q1;
+      stem_split2(w0, w1, q0, q1);                    // q = hi << 16 | lo per weight
+      wh[i] = (q0 >> 16) | (q1 & 0xffff0000u);
+      wl[i] = (q0 & 0xffffu) | (q1 << 16);
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int tap = lh ? (s8 == 0 ? 8 : -1) : s8, ky = tap / 3, kx = tap - 3 * ky;
+      poff[s8] = tap >= 0 ? (2 * wave + ky) * STEM_LDW + li + kx + 1 : STEM_IN_ROWS * STEM_LDW;
+    }
+    asm volatile("" ::"v"(wh[0]), "v"(wh[1]), "v"(wh[2]), "v"(wh[3]), "v"(wl[0]), "v"(wl[1]), "v"(wl[2]), "v"(wl[3]));
   }
   const int px = li & 1;
   // every constant has arrived before the band loop: the compiler's wait-count pass would otherwise carry their pending
@@ -292,22 +344,52 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const floa
     };
     // the two interleaved MFMA chains of a pair (column block tx)
     auto chains = [&](int tx, stem_f32x16& aa, stem_f32x16& ab) {
-      const float* base = sin_ + (2 * wave) * STEM_LDW + 32 * tx;   // convolution row 2 (yo0 + wave): staged row 2 wave is its row above
-      float va[5], vb[5];
-#pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        va[j] = toff[j] >= 0 ? base[toff[j]] : zero_in;
-        vb[j] = toff[j] >= 0 ? base[STEM_LDW + toff[j]] : zero_in;
-      }
       const stem_f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0], va[0], zero, 0, 0, 0);
-      ab = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0], vb[0], zero, 0, 0, 0);
+      if constexpr (SPLIT) {
+        typedef __bf16 stem_bf16x8 __attribute__((ext_vector_type(8)));
+        typedef unsigned stem_u32x4 __attribute__((ext_vector_type(4)));
+        const unsigned* bu = reinterpret_cast<const unsigned*>(sin_) + 32 * tx;
+        unsigned da[8], db[8];
 #pragma unroll
-      for (int j = 1; j < 5; ++j) {
-        aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j], va[j], aa, 0, 0, 0);
-        ab = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j], vb[j], ab, 0, 0, 0);
+        for (int s8 = 0; s8 < 8; ++s8) {
+          da[s8] = bu[poff[s8]];
+          db[s8] = bu[poff[s8] + STEM_LDW];
+        }
+        stem_u32x4 ha, la, hb, lb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // slot 2i in the low half of a register, 2i + 1 in the high half
+          ha[i] = __builtin_amdgcn_perm(da[2 * i + 1], da[2 * i], 0x07060302u);
+          la[i] = __builtin_amdgcn_perm(da[2 * i + 1], da[2 * i], 0x05040100u);
+          hb[i] = __builtin_amdgcn_perm(db[2 * i + 1], db[2 * i], 0x07060302u);
+          lb[i] = __builtin_amdgcn_perm(db[2 * i + 1], db[2 * i], 0x05040100u);
+        }
+        const stem_bf16x8 WH = __builtin_bit_cast(stem_bf16x8, (stem_u32x4){wh[0], wh[1], wh[2], wh[3]});
+        const stem_bf16x8 WL = __builtin_bit_cast(stem_bf16x8, (stem_u32x4){wl[0], wl[1], wl[2], wl[3]});
+        aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WL, __builtin_bit_cast(stem_bf16x8, ha), zero, 0, 0, 0);
+        ab = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WL, __builtin_bit_cast(stem_bf16x8, hb), zero, 0, 0, 0);
+        aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WH, __builtin_bit_cast(stem_bf16x8, la), aa, 0, 0, 0);
+        ab = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WH, __builtin_bit_cast(stem_bf16x8, lb), ab, 0, 0, 0);
+        aa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WH, __builtin_bit_cast(stem_bf16x8, ha), aa, 0, 0, 0);
+        ab = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WH, __builtin_bit_cast(stem_bf16x8, hb), ab, 0, 0, 0);
+      } else {
+        const float* base = sin_ + (2 * wave) * STEM_LDW + 32 * tx;   // convolution row 2 (yo0 + wave): staged row 2 wave is its row above
+        float va[5], vb[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          va[j] = toff[j] >= 0 ? base[toff[j]] : zero_in;
+          vb[j] = toff[j] >= 0 ? base[STEM_LDW + toff[j]] : zero_in;
+        }
+        aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0], va[0], zero, 0, 0, 0);
+        ab = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[0], vb[0], zero, 0, 0, 0);
+#pragma unroll
+        for (int j = 1; j < 5; ++j) {
+          aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j], va[j], aa, 0, 0, 0);
+          ab = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[j], vb[j], ab, 0, 0, 0);
+        }
       }
     };
+    // (SPLIT: 0, 12, 20 or 28 vector instructions per MFMA measured the same 281-289 us: the vector pipe sets the pace)
+    constexpr int NMF = SPLIT ? 6 : 10, NVA = SPLIT ? 20 : 12;      // the epilogue's vector instructions dealt between the MFMAs
     if (any_bad) {        // uniform; the plain order
 #pragma unroll 1
       for (int tx = 0; tx < 3; ++tx) {
@@ -322,16 +404,16 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const floa
       chains(1, a1, b1);
       epilogue(a0, b0, wave, 0, false);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) {
+      for (int k = 0; k < NMF; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NVA, 0);
       }
       chains(2, a2, b2);
       epilogue(a1, b1, wave, 1, false);
 #pragma unroll
-      for (int k = 0; k < 10; ++k) {
+      for (int k = 0; k < NMF; ++k) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NVA, 0);
       }
       // the next band's rows into the other buffer (last read before the previous barrier) ahead of the last epilogue:
       // the wait for the prefetch then leaves that epilogue's stores in flight
@@ -350,8 +432,10 @@ static int launch_stem_any(const StemParams& p, const float* images, int n, void
   const int nb = n >= 1024 ? 48 / STEM_ROWS : 1;             // bands per workgroup of the matrix-pipe form
   if (p.valu)
     hipLaunchKernelGGL(stem_kernel<OUT_BF16>, dim3((unsigned)blocks), dim3(256), 0, stream, p, images, n, out);
+  else if (OUT_BF16 && p.valu != 2)      // the bf16 mode: split operands on the bf16 matrix instructions
+    hipLaunchKernelGGL((stem_mfma_kernel<OUT_BF16, OUT_BF16>), dim3((unsigned)(blocks / nb)), dim3(256), 0, stream, p, images, n, nb, out);
   else
-    hipLaunchKernelGGL(stem_mfma_kernel<OUT_BF16>, dim3((unsigned)(blocks / nb)), dim3(256), 0, stream, p, images, n, nb, out);
+    hipLaunchKernelGGL((stem_mfma_kernel<OUT_BF16, false>), dim3((unsigned)(blocks / nb)), dim3(256), 0, stream, p, images, n, nb, out);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

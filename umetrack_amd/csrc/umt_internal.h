@@ -68,6 +68,7 @@ enum : unsigned {
   CONV_STEM_VALU = 16384u,  // UMT_STEM_VALU: the stem on the vector pipe (stem_kernel) instead of stem_mfma_kernel
   CONV_NO_WALK = 32768u,    // UMT_CONV_NOWALK: bf16 fused stride-2 layers one tile per workgroup instead of conv3x3s2_walk_bf16
   SEQ_ONE_KERNEL = 65536u,  // UMT_SEQ_ONEKERNEL: umt_head_sequence runs the regressor inside head_seq_kernel, step by step
+  STEM_NO_SPLIT = 262144u,  // UMT_STEM_NOSPLIT: the bf16 mode's stem on the fp32 matrix instructions (the fp32 modes' arithmetic)
   HEAD_NO_X3 = 131072u,     // UMT_HEAD_NOX3: the regressor's 3x3 layers on the fp32 kernels in the bf16 / fp32x3 modes too
 };
 unsigned conv_flags_from_env();

@@ -283,6 +283,18 @@ class UmeTrackModel:
         return self._forward(nat.HEAD_PREDICT_SCALE, frame_data, frame_desc, None, required_rows, out)
 
     # ---- stage-level calls (reference layouts), used by the parity tests ----
+    def stem(self, images: torch.Tensor) -> torch.Tensor:
+        """The backbone's first layer group alone (conv 1 -> 32, BN, ReLU, 2x2 max-pool; model_utils.py:119-124):
+        [n,96,96] -> [n,48,48,32] channels-last, float32, or bfloat16 in the "bf16" mode (the tensor its backbone reads)."""
+        dev, L = self._device, nat.lib()
+        images = nat.dev_tensor(images, torch.float32, dev)
+        n = images.shape[0]
+        out = torch.empty(n, 48, 48, 32, device=dev, dtype=torch.bfloat16 if self.precision == "bf16" else torch.float32)
+        with torch.cuda.device(dev):
+            nat.check(L.umt_stem_forward(self._h, nat.ptr(images), n, self._precision, nat.ptr(out), nat.stream_ptr(dev)),
+                      "umt_stem_forward")
+        return out
+
     def backbone(self, images: torch.Tensor) -> torch.Tensor:
         """_image_backbone(images.unsqueeze(1)), umetrack_model.py:127-129: [n,96,96] -> [n,72,6,6]."""
         if self._device is None:
