@@ -238,6 +238,13 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const floa
     cs[g] = *reinterpret_cast<const float4*>(p.scale + 8 * g + 4 * lh);
     ch[g] = *reinterpret_cast<const float4*>(p.shift + 8 * g + 4 * lh);
   }
+  if (SPLIT) {          // (x + bias) * scale + shift = x * scale + (bias * scale + shift): 2^-24 apart, under a 2^-9 rounding
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ch[g].x = fmaf(cb[g].x, cs[g].x, ch[g].x); ch[g].y = fmaf(cb[g].y, cs[g].y, ch[g].y);
+      ch[g].z = fmaf(cb[g].z, cs[g].z, ch[g].z); ch[g].w = fmaf(cb[g].w, cs[g].w, ch[g].w);
+    }
+  }
   // float offset of each of the lane's five taps from its tile's origin in the staged rows (tap (ky, kx) of pixel (y, x):
   // staged row y + ky, column x + kx + 1; the tenth slot reads the zero at the start of the tile's first row)
   int toff[5];
@@ -293,10 +300,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemParams p, const floa
       for (int g = 0; g < 4; ++g) {
         const stem_f32x2 sb0 = {cb[g].x, cb[g].y}, sb1 = {cb[g].z, cb[g].w}, ss0 = {cs[g].x, cs[g].y}, ss1 = {cs[g].z, cs[g].w},
                          sh0 = {ch[g].x, ch[g].y}, sh1 = {ch[g].z, ch[g].w};
-        const stem_f32x2 a0 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g], aa[4 * g + 1]} + sb0, ss0, sh0);
-        const stem_f32x2 a1 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g + 2], aa[4 * g + 3]} + sb1, ss1, sh1);
-        const stem_f32x2 b0 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g], ab[4 * g + 1]} + sb0, ss0, sh0);
-        const stem_f32x2 b1 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g + 2], ab[4 * g + 3]} + sb1, ss1, sh1);
+        stem_f32x2 a0, a1, b0, b1;
+        if constexpr (SPLIT) {        // the bias is folded into the shift before the band loop: one instruction per pair of values
+          a0 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g], aa[4 * g + 1]}, ss0, sh0);
+          a1 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g + 2], aa[4 * g + 3]}, ss1, sh1);
+          b0 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g], ab[4 * g + 1]}, ss0, sh0);
+          b1 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g + 2], ab[4 * g + 3]}, ss1, sh1);
+        } else {                      // the reference's order: (x + bias) * scale + shift
+          a0 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g], aa[4 * g + 1]} + sb0, ss0, sh0);
+          a1 = __builtin_elementwise_fma((stem_f32x2){aa[4 * g + 2], aa[4 * g + 3]} + sb1, ss1, sh1);
+          b0 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g], ab[4 * g + 1]} + sb0, ss0, sh0);
+          b1 = __builtin_elementwise_fma((stem_f32x2){ab[4 * g + 2], ab[4 * g + 3]} + sb1, ss1, sh1);
+        }
         r4[g][0] = fmaxf(fmaxf(a0.x, b0.x), 0.f);
         r4[g][1] = fmaxf(fmaxf(a0.y, b0.y), 0.f);
         r4[g][2] = fmaxf(fmaxf(a1.x, b1.x), 0.f);
