@@ -50,23 +50,44 @@ __device__ inline bool landmark_visible(const Fisheye& s, double wx, double wy, 
   return ox >= 0 && ox <= s.w - 1 && oy >= 0 && oy <= s.h - 1 && z > 0;     // perspective_crop.py:68-74
 }
 
-// general 4x4 inverse (Gauss-Jordan, partial pivoting) - numpy.linalg.inv on the reference side
-__device__ inline void inv4(const double* a, double* out) {
+// general 4x4 inverse (Gauss-Jordan, partial pivoting) - numpy.linalg.inv on the reference side.
+// Every index is a compile-time constant (the loops unroll), so the 4 x 8 tableau lives in registers: with a run-time pivot
+// row it sat in scratch memory and the kernel's six inversions per view were a stream of scratch accesses (0.33 ms per
+// 8192 hands).  The pivot row comes up by conditional swaps with each lower row in turn: the row that ends in place c is
+// the first of largest magnitude, as before, and where the OTHER rows sit does not enter the arithmetic (each is updated
+// by its own multiple of the pivot row), so the result is bit-identical to the single-swap form.
+__device__ __forceinline__ void inv4(const double* a, double* out) {
   double m[4][8];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) { m[i][j] = a[i * 4 + j]; m[i][4 + j] = i == j ? 1.0 : 0.0; }
+#pragma unroll
   for (int c = 0; c < 4; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < 4; ++r) if (fabs(m[r][c]) > fabs(m[piv][c])) piv = r;
-    if (piv != c) for (int j = 0; j < 8; ++j) { const double t = m[c][j]; m[c][j] = m[piv][j]; m[piv][j] = t; }
+#pragma unroll
+    for (int r = c + 1; r < 4; ++r) {
+      const bool sw = fabs(m[r][c]) > fabs(m[c][c]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double t = m[c][j];
+        m[c][j] = sw ? m[r][j] : t;
+        m[r][j] = sw ? t : m[r][j];
+      }
+    }
     const double d = 1.0 / m[c][c];
+#pragma unroll
     for (int j = 0; j < 8; ++j) m[c][j] *= d;
+#pragma unroll
     for (int r = 0; r < 4; ++r) if (r != c) {
       const double f = m[r][c];
+#pragma unroll
       for (int j = 0; j < 8; ++j) m[r][j] -= f * m[c][j];
     }
   }
-  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[i * 4 + j] = m[i][4 + j];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[i * 4 + j] = m[i][4 + j];
 }
 
 __device__ inline double wave_max(double v) {
