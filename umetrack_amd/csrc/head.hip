@@ -354,14 +354,21 @@ int launch_avgpool(const float* rows, int cs, int c, int bs, float* raw, hipStre
 // 3x3 SVD by one-sided Jacobi (Hestenes): rotates column pairs of A = H and of V until the
 // columns of A are orthogonal; then A = U*diag(s).  Only R = V*diag(1,1,det(V U^T))*U^T is
 // used, which is unique whenever the reference's result is (SURVEY.md section 7 "hard parts").
-__device__ inline void kabsch_rotation(const double* H, double* R) {
+// Every array index is a compile-time constant (unrolled loops; the smallest singular value's column is placed by
+// selects, not by a run-time index), so nothing lives in scratch memory: the kernel is one thread per hand and in the
+// tracker's per-frame call its latency is on the critical path.  Same operations in the same order as the indexed form.
+__device__ __forceinline__ void kabsch_rotation(const double* H, double* R) {
   double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
   for (int i = 0; i < 9; ++i) A[i] = H[i];
   for (int sweep = 0; sweep < 30; ++sweep) {
     double off = 0;
+#pragma unroll
     for (int p = 0; p < 2; ++p)
+#pragma unroll
       for (int q = p + 1; q < 3; ++q) {
         double al = 0, be = 0, ga = 0;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
           al += A[i * 3 + p] * A[i * 3 + p];
           be += A[i * 3 + q] * A[i * 3 + q];
@@ -372,6 +379,7 @@ __device__ inline void kabsch_rotation(const double* H, double* R) {
         const double zeta = (be - al) / (2.0 * ga);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
         const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
         for (int i = 0; i < 3; ++i) {
           const double ap = A[i * 3 + p], aq = A[i * 3 + q];
           A[i * 3 + p] = c * ap - s * aq;
@@ -383,67 +391,102 @@ __device__ inline void kabsch_rotation(const double* H, double* R) {
       }
     if (off < 1e-15) break;
   }
-  double sv[3], U[9];
+  double sv[3], N[9], U[9];
   int kmin = 0;
-  for (int j = 0; j < 3; ++j) {
-    sv[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
-    if (sv[j] < sv[kmin]) kmin = j;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) sv[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+  {
+    double svmin = sv[0];                       // first of the smallest, as `if (sv[j] < sv[kmin]) kmin = j`
+    if (sv[1] < svmin) { svmin = sv[1]; kmin = 1; }
+    if (sv[2] < svmin) { svmin = sv[2]; kmin = 2; }
   }
-  const int ka = (kmin + 1) % 3, kb = (kmin + 2) % 3;
-  for (int j = 0; j < 3; ++j)
-    if (j != kmin) {
-      const double inv = sv[j] > 0 ? 1.0 / sv[j] : 0.0;
-      for (int i = 0; i < 3; ++i) U[i * 3 + j] = A[i * 3 + j] * inv;
-    }
-  const double smax = fmax(sv[ka], sv[kb]);
-  if (sv[kmin] > 1e-12 * smax) {
-    for (int i = 0; i < 3; ++i) U[i * 3 + kmin] = A[i * 3 + kmin] / sv[kmin];
-  } else {  // rank-2 H: complete U with the cross product (any sign gives the same R after the det fix)
-    U[0 * 3 + kmin] = U[1 * 3 + ka] * U[2 * 3 + kb] - U[2 * 3 + ka] * U[1 * 3 + kb];
-    U[1 * 3 + kmin] = U[2 * 3 + ka] * U[0 * 3 + kb] - U[0 * 3 + ka] * U[2 * 3 + kb];
-    U[2 * 3 + kmin] = U[0 * 3 + ka] * U[1 * 3 + kb] - U[1 * 3 + ka] * U[0 * 3 + kb];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {                 // the columns as they are when j is not the smallest
+    const double inv = sv[j] > 0 ? 1.0 / sv[j] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) N[i * 3 + j] = A[i * 3 + j] * inv;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    constexpr int nx[3] = {1, 2, 0}, nn[3] = {2, 0, 1};
+    const int ka = nx[j], kb = nn[j];
+    // column j if it IS the smallest: divided by its singular value, or for a rank-2 H the cross product of the other two
+    // (any sign gives the same R after the det fix)
+    const bool full = sv[j] > 1e-12 * fmax(sv[ka], sv[kb]);
+    const double x0 = N[1 * 3 + ka] * N[2 * 3 + kb] - N[2 * 3 + ka] * N[1 * 3 + kb];
+    const double x1 = N[2 * 3 + ka] * N[0 * 3 + kb] - N[0 * 3 + ka] * N[2 * 3 + kb];
+    const double x2 = N[0 * 3 + ka] * N[1 * 3 + kb] - N[1 * 3 + ka] * N[0 * 3 + kb];
+    const double s0 = full ? A[0 * 3 + j] / sv[j] : x0, s1 = full ? A[1 * 3 + j] / sv[j] : x1, s2 = full ? A[2 * 3 + j] / sv[j] : x2;
+    U[0 * 3 + j] = j == kmin ? s0 : N[0 * 3 + j];
+    U[1 * 3 + j] = j == kmin ? s1 : N[1 * 3 + j];
+    U[2 * 3 + j] = j == kmin ? s2 : N[2 * 3 + j];
   }
   auto det3 = [](const double* m) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
   };
   const double d = det3(V) * det3(U);   // det(V U^T), +-1 up to rounding
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       double s = 0;
+#pragma unroll
       for (int k = 0; k < 3; ++k) s += V[i * 3 + k] * (k == kmin ? d : 1.0) * U[j * 3 + k];
       R[i * 3 + j] = s;
     }
 }
 
-__global__ void decode_kernel(const float* raw, int nraw, int predict_scale, const float* cam0, const int64_t* hand_idx,
-                              int bs, float* joint_angles, float* wrist_xfs, float* sigmas, float* skel_scales,
-                              int32_t* status) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bs) return;
-  const float* r = raw + (size_t)b * nraw;
+// A half-wave (32 lanes) per hand.  The Procrustes fit and the wrist transform are one dependent float64 chain and every
+// lane of the half-wave walks it (lane 0 stores); what is independent per element - the finiteness test, the joint angles,
+// the 21 softplus values (a float64 exp and log1p each) - is spread over the lanes: one thread per hand spent a third of
+// its 33 us there, and in the tracker's per-frame call that latency is on the critical path.
+constexpr int DECODE_LANES = 32;
+
+__global__ __launch_bounds__(64) void decode_kernel(const float* raw, int nraw, int predict_scale, const float* cam0,
+                                                    const int64_t* hand_idx, int bs, float* joint_angles, float* wrist_xfs,
+                                                    float* sigmas, float* skel_scales, int32_t* status) {
+  const int half = threadIdx.x / DECODE_LANES, l = threadIdx.x % DECODE_LANES;
+  const int b = blockIdx.x * (64 / DECODE_LANES) + half;
+  const bool have = b < bs;
+  const float* r = raw + (size_t)(have ? b : 0) * nraw;
   // torch's ReLU / MaxPool propagate NaN; the integer ReLU and the pooled max of the backbone kernels may drop one
   // (conv_f32_common.h, stem.hip).  A non-finite regressor row is therefore reported, and the whole row of outputs
   // is NaN, so that a corrupted crop or weight cannot come out as a plausible pose.
-  bool finite = true;
-  for (int i = 0; i < nraw; ++i) finite = finite && isfinite(r[i]);
+  bool mine = true;
+  for (int i = l; i < nraw; i += DECODE_LANES) mine = mine && isfinite(r[i]);
+  const unsigned long long notfin = __ballot(!mine);
+  const bool finite = ((notfin >> (DECODE_LANES * half)) & 0xffffffffull) == 0;
+  if (!have) return;
   if (!finite) {
-    if (status) atomicOr(status, UMT_STATUS_NONFINITE_OUTPUT);
+    if (status && l == 0) atomicOr(status, UMT_STATUS_NONFINITE_OUTPUT);
     const float q = __builtin_nanf("");
-    for (int i = 0; i < 22; ++i) joint_angles[b * 22 + i] = q;
-    for (int i = 0; i < 16; ++i) wrist_xfs[b * 16 + i] = q;
-    for (int i = 0; i < 21; ++i) sigmas[b * 21 + i] = q;
-    if (predict_scale) skel_scales[b] = q;
+    if (l < 22) joint_angles[b * 22 + l] = q;
+    if (l < 16) wrist_xfs[b * 16 + l] = q;
+    if (l < 21) sigmas[b * 21 + l] = q;
+    if (predict_scale && l == 0) skel_scales[b] = q;
     return;
   }
   // regressor.py:76-85
-  for (int i = 0; i < 20; ++i) joint_angles[b * 22 + i] = r[i];
-  joint_angles[b * 22 + 20] = 0.f;
-  joint_angles[b * 22 + 21] = 0.f;
+  if (l < 22) joint_angles[b * 22 + l] = l < 20 ? r[l] : 0.f;
+  {
+    int o = 41;
+    if (predict_scale) {   // regressor.py:107-114
+      if (l == 0) skel_scales[b] = expf(r[41]);
+      o = 42;
+    }
+    if (l < 21) {          // regressor.py:117-121: clamp(softplus(x), 1e-5), torch threshold 20
+      const float x = r[o + l];
+      const float sp = x > 20.f ? x : (float)log1p(exp((double)x));
+      sigmas[b * 21 + l] = fmaxf(sp, 1e-5f);
+    }
+  }
   // regressor.py:19-47, 88-104: seven source points, float32 like the reference's tensor
   const double raw_src[7][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, -1, 0}, {-1, 0, -1}, {0, -1, -1}};
   double src[7][3], dst[7][3], ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
+#pragma unroll
   for (int i = 0; i < 7; ++i) {
     const double nrm = sqrt(raw_src[i][0] * raw_src[i][0] + raw_src[i][1] * raw_src[i][1] + raw_src[i][2] * raw_src[i][2]);
+#pragma unroll
     for (int k = 0; k < 3; ++k) {
       src[i][k] = nrm > 0 ? (double)(float)(raw_src[i][k] / nrm * 0.1) : 0.0;
       dst[i][k] = (double)r[20 + i * 3 + k];
@@ -451,15 +494,21 @@ __global__ void decode_kernel(const float* raw, int nraw, int predict_scale, con
       md[k] += dst[i][k];
     }
   }
+#pragma unroll
   for (int k = 0; k < 3; ++k) { ms[k] /= 7.0; md[k] /= 7.0; }
   double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // model_utils.py:36-39: from_centered^T @ to_centered
+#pragma unroll
   for (int i = 0; i < 7; ++i)
+#pragma unroll
     for (int a = 0; a < 3; ++a)
+#pragma unroll
       for (int c = 0; c < 3; ++c) H[a * 3 + c] += (src[i][a] - ms[a]) * (dst[i][c] - md[c]);
   double R[9];
   kabsch_rotation(H, R);
   double wc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+#pragma unroll
   for (int i = 0; i < 3; ++i) {
+#pragma unroll
     for (int j = 0; j < 3; ++j) wc[i * 4 + j] = R[i * 3 + j];
     wc[i * 4 + 3] = md[i] - (R[i * 3 + 0] * ms[0] + R[i * 3 + 1] * ms[1] + R[i * 3 + 2] * ms[2]);
   }
@@ -469,17 +518,11 @@ __global__ void decode_kernel(const float* raw, int nraw, int predict_scale, con
   mat4_inv(e, ei);
   mat4_mul(ei, wc, ww);
   const bool right = hand_idx[b] == 1;
-  for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j) wrist_xfs[b * 16 + i * 4 + j] = (float)((right && j == 0) ? -ww[i * 4 + j] : ww[i * 4 + j]);
-  int o = 41;
-  if (predict_scale) {   // regressor.py:107-114
-    skel_scales[b] = expf(r[41]);
-    o = 42;
-  }
-  for (int i = 0; i < 21; ++i) {   // regressor.py:117-121: clamp(softplus(x), 1e-5), torch threshold 20
-    const float x = r[o + i];
-    const float sp = x > 20.f ? x : (float)log1p(exp((double)x));
-    sigmas[b * 21 + i] = fmaxf(sp, 1e-5f);
+  if (l == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wrist_xfs[b * 16 + i * 4 + j] = (float)((right && j == 0) ? -ww[i * 4 + j] : ww[i * 4 + j]);
   }
 }
 
@@ -488,7 +531,7 @@ int launch_decode(const float* raw, int nraw, int predict_scale, const float* ca
                   hipStream_t s) {
   UMT_REQUIRE(nraw == (predict_scale ? 63 : 62), UMT_ERR_INVALID, "decode: nraw = %d", nraw);
   UMT_REQUIRE(!predict_scale || skel_scales, UMT_ERR_INVALID, "decode: scale head needs a skel_scales buffer");
-  hipLaunchKernelGGL(decode_kernel, dim3(grid_for(bs, 64)), dim3(64), 0, s, raw, nraw, predict_scale, cam0_ext,
+  hipLaunchKernelGGL(decode_kernel, dim3(grid_for(bs, 64 / DECODE_LANES)), dim3(64), 0, s, raw, nraw, predict_scale, cam0_ext,
                      hand_idx, bs, joint_angles, wrist_xfs, sigmas, skel_scales, status);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;

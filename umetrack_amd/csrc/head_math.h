@@ -16,31 +16,46 @@ __device__ inline void mat4_mul(const double* a, const double* b, double* c) {
 
 // Gauss-Jordan with partial pivoting; a singular input yields inf/nan where torch.inverse would raise.
 // Returns false when a pivot is exactly zero or not finite (the matrix is singular to working precision).
-__device__ inline bool mat4_inv(const double* m, double* inv) {
+// Every index is a compile-time constant (the loops unroll) so the tableau stays in registers: the pivot row comes up by
+// conditional swaps with each lower row in turn - the row that lands in place is the first of largest magnitude, as with a
+// single swap, and where the other rows sit does not enter the arithmetic (bit-identical; see inv4 in cropcam.hip).
+__device__ __forceinline__ bool mat4_inv(const double* m, double* inv) {
   bool regular = true;
   double a[4][8];
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) {
       a[i][j] = m[i * 4 + j];
       a[i][4 + j] = (i == j) ? 1.0 : 0.0;
     }
+#pragma unroll
   for (int col = 0; col < 4; ++col) {
-    int piv = col;
-    double best = fabs(a[col][col]);
-    for (int r = col + 1; r < 4; ++r)
-      if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
-    if (piv != col)
-      for (int j = 0; j < 8; ++j) { double t = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = t; }
+#pragma unroll
+    for (int r = col + 1; r < 4; ++r) {
+      const bool sw = fabs(a[r][col]) > fabs(a[col][col]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double t = a[col][j];
+        a[col][j] = sw ? a[r][j] : t;
+        a[r][j] = sw ? t : a[r][j];
+      }
+    }
     if (!(fabs(a[col][col]) > 0.0) || !isfinite(a[col][col])) regular = false;
     const double d = 1.0 / a[col][col];
+#pragma unroll
     for (int j = 0; j < 8; ++j) a[col][j] *= d;
+#pragma unroll
     for (int r = 0; r < 4; ++r)
       if (r != col) {
         const double f = a[r][col];
+#pragma unroll
         for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
       }
   }
+#pragma unroll
   for (int i = 0; i < 4; ++i)
+#pragma unroll
     for (int j = 0; j < 4; ++j) inv[i * 4 + j] = a[i][4 + j];
   return regular;
 }
