@@ -162,8 +162,10 @@ int launch_ftl_concat(const float* feat_rows, const float* crop_xf, const int64_
 }
 
 // out[b] = FTL(S0) of the fused conv output (2 views) or FTL(S) of the crop's own features (1 view)
+// zero_rest: also writes zeros to the channels [0, out_c0) and [out_c0 + 72, out_cs) of every output row (at most 24: one
+// per thread of a pixel), which saves the caller a memset launch of the whole tensor
 __global__ void ftl_select_kernel(const float* conv, const float* feat, const float* sample_xf, const int64_t* sr,
-                                  const int32_t* views, int bs, float* out, int out_cs, int out_c0) {
+                                  const int32_t* views, int bs, float* out, int out_cs, int out_c0, int zero_rest) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)bs * 36 * 24) return;
   const int c = (int)(t % 24);
@@ -175,14 +177,17 @@ __global__ void ftl_select_kernel(const float* conv, const float* feat, const fl
   ftl_point(sample_xf + b * 12, f[c], f[c + 24], f[c + 48], x, y, z);
   float* o = out + ((size_t)b * 36 + p) * out_cs + out_c0;
   o[c] = x; o[c + 24] = y; o[c + 48] = z;
+  if (zero_rest && c < out_cs - 72) o[(c < out_c0 ? c : c + 72) - out_c0] = 0.f;
 }
 
 int launch_ftl_select(const float* conv_rows, const float* feat_rows, const float* sample_xf,
                       const int64_t* sample_range, const int32_t* sample_views, int n, int bs,
-                      float* out_rows, int out_cs, int out_c0, hipStream_t s) {
+                      float* out_rows, int out_cs, int out_c0, hipStream_t s, bool zero_rest) {
   (void)n;
+  UMT_REQUIRE(!zero_rest || (out_cs - 72 >= 0 && out_cs - 72 <= 24 && out_c0 >= 0 && out_c0 + 72 <= out_cs), UMT_ERR_INVALID,
+              "ftl_select: cannot zero %d other channels", out_cs - 72);
   hipLaunchKernelGGL(ftl_select_kernel, dim3(grid_for((int64_t)bs * 36 * 24, 256)), dim3(256), 0, s, conv_rows,
-                     feat_rows, sample_xf, sample_range, sample_views, bs, out_rows, out_cs, out_c0);
+                     feat_rows, sample_xf, sample_range, sample_views, bs, out_rows, out_cs, out_c0, zero_rest ? 1 : 0);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -272,8 +277,10 @@ int launch_temporal_gather(float* mem, float* prev_ext, unsigned long long* owne
 }
 
 // channels 0..17 of the temporal output overwrite the memory row, 18..89 go on (temporal.py:88-89,134)
+// zero_pad: also writes zeros to the channels [72, out_cs) of every output row (the skeleton channels, which the skeleton
+// kernel fills afterwards, and the padding behind them) instead of a memset launch of the whole tensor by the caller
 __global__ void temporal_split_kernel(const float* tout, int tout_cs, float* mem, const int32_t* row_of, int bs,
-                                      float* out, int out_cs) {
+                                      float* out, int out_cs, int zero_pad) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= bs * 36 * 90) return;
   const int c = t % 90;
@@ -285,13 +292,15 @@ __global__ void temporal_split_kernel(const float* tout, int tout_cs, float* mem
     if (row >= 0 && !(row & ROW_NOT_OWNER)) mem[(size_t)row * 18 * 36 + c * 36 + p] = v;      // the claiming sample only
   } else {
     out[((size_t)b * 36 + p) * out_cs + (c - 18)] = v;
+    if (zero_pad && 72 + (c - 18) < out_cs) out[((size_t)b * 36 + p) * out_cs + 72 + (c - 18)] = 0.f;
   }
 }
 
 int launch_temporal_split(const float* tout_rows, int tout_cs, float* mem, const int32_t* row_of, int bs,
-                          float* out_rows, int out_cs, hipStream_t s) {
+                          float* out_rows, int out_cs, hipStream_t s, bool zero_pad) {
+  UMT_REQUIRE(!zero_pad || (out_cs >= 72 && out_cs <= 144), UMT_ERR_INVALID, "temporal_split: cannot zero %d channels", out_cs - 72);
   hipLaunchKernelGGL(temporal_split_kernel, dim3(grid_for((int64_t)bs * 36 * 90, 256)), dim3(256), 0, s, tout_rows,
-                     tout_cs, mem, row_of, bs, out_rows, out_cs);
+                     tout_cs, mem, row_of, bs, out_rows, out_cs, zero_pad ? 1 : 0);
   UMT_CHECK_HIP(hipGetLastError());
   return 0;
 }

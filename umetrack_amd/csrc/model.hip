@@ -664,14 +664,14 @@ static int fuse_rows(umt_model* m, const float* feat, const float* K, const floa
     UMT_TRY(launch_conv(m->fuse2, w.f1, bs, 6, 6, nullptr, w.f2, s));
     UMT_TRY(launch_conv(m->fuse3, w.f2, bs, 6, 6, nullptr, w.f3, s));
   }
-  UMT_CHECK_HIP(hipMemsetAsync(w.tin, 0, (size_t)bs * 36 * 96 * sizeof(float), s));
-  UMT_TRY(launch_ftl_select(w.f3, feat, w.sample_xf, sr, w.views, n, bs, w.tin, 96, 18, s));
+  // (the memory channels 0..17 and the padding 90..95 are zeroed by the same launch: no memset of the tensor)
+  UMT_TRY(launch_ftl_select(w.f3, feat, w.sample_xf, sr, w.views, n, bs, w.tin, 96, 18, s, true));
   return 0;
 }
 
 // tin (channels 18..89 set) -> temporal output in out_rows[.., 0..71] with stride out_cs; updates the state
 static int temporal_rows(umt_model* m, const float* cam0, const int64_t* midx, const uint8_t* use, int bs,
-                         const HeadWs& w, float* out_rows, int out_cs, hipStream_t s) {
+                         const HeadWs& w, float* out_rows, int out_cs, hipStream_t s, bool zero_pad = false) {
   UMT_REQUIRE(m->mem_rows > 0, UMT_ERR_STATE, "temporal: no memory rows reserved (umt_model_reserve_memory)");
   m->mem_epoch += 1;                      // one claim epoch per step; 2^32 steps before it could wrap
   if (m->mem_epoch == 0) m->mem_epoch = 1;
@@ -684,7 +684,7 @@ static int temporal_rows(umt_model* m, const float* cam0, const int64_t* midx, c
     UMT_TRY(launch_conv(m->temp[1], w.t1, bs, 6, 6, nullptr, w.t2, s));
     UMT_TRY(launch_conv(m->temp[2], w.t2, bs, 6, 6, nullptr, w.t1, s));
   }
-  UMT_TRY(launch_temporal_split(w.t1, 96, m->mem, w.row_of, bs, out_rows, out_cs, s));
+  UMT_TRY(launch_temporal_split(w.t1, 96, m->mem, w.row_of, bs, out_rows, out_cs, s, zero_pad));
   return 0;
 }
 
@@ -1168,8 +1168,7 @@ extern "C" int umt_model_forward(umt_model* m, int head, int precision, const fl
   if (ev) UMT_CHECK_HIP(hipEventRecord(ev[1], s));
   UMT_TRY(fuse_rows(m, bw.feat, intrinsics, extrinsics, sample_range, n, bs, hw, s));
   UMT_TRY(launch_gather_cam0(extrinsics, sample_range, n, bs, hw.cam0, s));
-  UMT_CHECK_HIP(hipMemsetAsync(hw.rin, 0, (size_t)bs * 36 * 80 * sizeof(float), s));
-  UMT_TRY(temporal_rows(m, hw.cam0, memory_idx, use_memory, bs, hw, hw.rin, cs, s));
+  UMT_TRY(temporal_rows(m, hw.cam0, memory_idx, use_memory, bs, hw, hw.rin, cs, s, true));   // zeroes rin's channels 72.. too
   UMT_TRY(regress_rows(m, head, skel_axes, skel_rest, n_skel, hw.cam0, hand_idx, bs, hw, joint_angles, wrist_xfs, sigmas,
                        skel_scales, nullptr, s, precision != UMT_PREC_FP32));
   if (ev) UMT_CHECK_HIP(hipEventRecord(ev[2], s));

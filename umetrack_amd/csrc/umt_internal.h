@@ -194,14 +194,14 @@ int launch_ftl_concat(const float* feat_rows, const float* crop_xf, const int64_
                       const int32_t* sample_views, int n, int bs, float* cat_rows, hipStream_t s);
 int launch_ftl_select(const float* conv_rows, const float* feat_rows, const float* sample_xf,
                       const int64_t* sample_range, const int32_t* sample_views, int n, int bs,
-                      float* out_rows, int out_cs, int out_c0, hipStream_t s);
+                      float* out_rows, int out_cs, int out_c0, hipStream_t s, bool zero_rest = false);
 // rel_xf: scratch [bs][12] floats + bs bytes, row_of: scratch [bs] int32 (validated memory row per sample);
 // owner: [mem_rows] claim words of the model handle, epoch: this step's claim epoch; status: UMT_STATUS_* word
 int launch_temporal_gather(float* mem, float* prev_ext, unsigned long long* owner, unsigned epoch, int mem_rows,
                            const float* cam0_ext, const int64_t* memory_idx, const uint8_t* use_memory, int bs,
                            float* tin_rows, int tin_cs, float* rel_xf, int32_t* row_of, int32_t* status, hipStream_t s);
 int launch_temporal_split(const float* tout_rows, int tout_cs, float* mem, const int32_t* row_of, int bs,
-                          float* out_rows, int out_cs, hipStream_t s);
+                          float* out_rows, int out_cs, hipStream_t s, bool zero_pad = false);
 struct SkelParams {
   const float* w;      // dev [144][132]
   const float* bias;   // dev [144]
