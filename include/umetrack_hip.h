@@ -45,6 +45,8 @@ enum {
  * UMT_PREC_FP32_BF16X3: every tensor stays fp32; inside the stride-1 3x3 backbone layers each fp32 operand is
  *   the exact sum of three bf16 pieces and a product is six bf16 matrix instructions accumulated in fp32
  *   (the dropped cross terms are <= 2^-23 of the product).  fp32-level accuracy, not bit-identical to FP32.
+ *   Launches of fewer than 16 384 pixels (a per-frame call's four crops) run the FP32 kernels, whose few-pixel
+ *   forms are faster there.
  * In both non-FP32 modes umt_model_forward also runs the known-skeleton regressor's 3x3 layers that way when bs >= 228
  * (8192 head pixels: the batches the wide tiles are for); the stage entry points (umt_regress_decode, umt_head_sequence)
  * take no precision and always use the FP32 kernels. */

@@ -26,8 +26,10 @@ def models(golden_sequence):
     return model_from_state_dict(state).to("cuda"), state
 
 
-@pytest.mark.parametrize("n", [1, 5, 16, 67])
+@pytest.mark.parametrize("n", [1, 5, 16, 67, 460])
 def test_x3_backbone_is_as_close_to_float64_as_the_fp32_kernels(models, n):
+    """A layer runs on the split-operand kernels from 16 384 pixels per launch on (below that the fp32 kernels' few-pixel
+    forms are faster: the tracker's per-frame call): none at 1 and 5 crops, stage 1 at 16, stages 1-2 at 67, all at 460."""
     gm, state = models
     img = torch.rand(n, 96, 96, generator=torch.Generator().manual_seed(200 + n))
     f32 = gm.backbone(img.cuda()).cpu().numpy()
@@ -38,7 +40,7 @@ def test_x3_backbone_is_as_close_to_float64_as_the_fp32_kernels(models, n):
     finally:
         gm.precision = "fp32"
     assert np.array_equal(x3, x3b)                       # deterministic
-    assert not np.array_equal(x3, f32)                   # the mode really runs the split kernels
+    assert np.array_equal(x3, f32) == (n * 48 * 48 < 16384)      # the mode really runs the split kernels
     sd = om.to_torch_state(state, torch.float64)
     with torch.no_grad():
         truth = om.backbone(sd, img.double()).numpy()

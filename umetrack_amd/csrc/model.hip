@@ -486,8 +486,11 @@ static int conv_mark(umt_model* m, hipStream_t s, const char* kind, const ConvLa
 // Blocks [b0, b1) on n crops whose rows start at x; returns the buffer that holds the result.
 // x/t/y rotate; the down-sample branch goes to d.
 // x3: stride-1 3x3 layers on the bf16 matrix pipe with three-way split operands (conv_x3.hip); every tensor stays fp32.
+// A launch with too few pixels to fill the chip with the split kernels' 128-pixel tiles (the tracker's per-frame call: 4 crops)
+// stays on the fp32 kernels, which have few-pixel forms (conv_small.hip): 1.05 -> 0.6 ms per frame in the fp32x3 mode.
+constexpr int64_t X3_MIN_PIXELS = 16384;
 static int conv_f32(const ConvLayer& L, bool x3, const float* in, int n, int hw, const float* res, float* out, hipStream_t s) {
-  if (x3 && conv_x3_applicable(L, hw)) return launch_conv_x3(L, in, n, hw, hw, res, out, s);
+  if (x3 && (int64_t)n * hw * hw >= X3_MIN_PIXELS && conv_x3_applicable(L, hw)) return launch_conv_x3(L, in, n, hw, hw, res, out, s);
   return launch_conv(L, in, n, hw, hw, res, out, s);
 }
 
@@ -497,7 +500,7 @@ static int run_blocks(umt_model* m, bool x3, size_t b0, size_t b1, int n, float*
     const BlockLayers& B = m->blocks[i];
     const int hw = m->block_hw[i];
     const float* res = x;
-    if (B.has_down && x3 && conv_s2_x3_applicable(B.conv1, &B.down, hw, hw)) {
+    if (B.has_down && x3 && (int64_t)n * hw * hw / 4 >= X3_MIN_PIXELS && conv_s2_x3_applicable(B.conv1, &B.down, hw, hw)) {
       UMT_TRY(launch_conv_s2_fused_x3(B.conv1, &B.down, x, n, hw, hw, t, d, s));
       UMT_TRY(conv_mark(m, s, "c1+ds", B.conv1, &B.down, n, hw));
       res = d;
@@ -705,10 +708,14 @@ static int regress_rows(umt_model* m, int head, const float* skel_axes, const fl
   }
   const BlockLayers* B = m->reg_blocks[head];
   x3 = x3 && !(m->conv_flags & HEAD_NO_X3) && (int64_t)bs * 36 >= HEAD_X3_MIN_PIXELS;
-  UMT_TRY(conv_f32(B[0].conv1, x3, w.rin, bs, 6, nullptr, w.r1, s));
-  UMT_TRY(conv_f32(B[0].conv2, x3, w.r1, bs, 6, w.rin, w.r2, s));
-  UMT_TRY(conv_f32(B[1].conv1, x3, w.r2, bs, 6, nullptr, w.r1, s));
-  UMT_TRY(conv_f32(B[1].conv2, x3, w.r1, bs, 6, w.r2, w.r3, s));
+  auto conv = [&](const ConvLayer& L, const float* in, const float* res, float* out) {
+    if (x3 && conv_x3_applicable(L, 6)) return launch_conv_x3(L, in, bs, 6, 6, res, out, s);
+    return launch_conv(L, in, bs, 6, 6, res, out, s);
+  };
+  UMT_TRY(conv(B[0].conv1, w.rin, nullptr, w.r1));
+  UMT_TRY(conv(B[0].conv2, w.r1, w.rin, w.r2));
+  UMT_TRY(conv(B[1].conv1, w.r2, nullptr, w.r1));
+  UMT_TRY(conv(B[1].conv2, w.r1, w.r2, w.r3));
   UMT_TRY(launch_conv(m->reg_out[head], w.r3, bs, 6, 6, nullptr, w.rout, s));
   UMT_TRY(launch_avgpool(w.rout, 64, nraw, bs, w.raw, s));
   if (raw_out) UMT_CHECK_HIP(hipMemcpyAsync(raw_out, w.raw, (size_t)bs * nraw * sizeof(float), hipMemcpyDeviceToDevice, s));
