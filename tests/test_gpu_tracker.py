@@ -385,3 +385,37 @@ def test_head_sequence_equals_stepwise_calls(monkeypatch, one_kernel, head_name,
     mem_step, prev_step = model.memory_state()
     assert torch.equal(mem_seq, mem_step) and torch.equal(prev_seq, prev_step)
     model.check_status()
+
+
+def test_head_sequence_regressor_batches_cover_long_calls():
+    """umt_head_sequence runs its regressor over the T x R hand-frames in batches of at most 8192: a call with 9000 of them
+    (two batches, the second one short) must still equal the per-step calls bit for bit."""
+    from umetrack_amd import _native as nat
+    from umetrack_amd.lib.common.hand import load_generic_hand_model, scaled_hand_model
+    from umetrack_amd.lib.models.model_loader import model_from_state_dict
+    from umetrack_amd.lib.models.umetrack_model import InputSkeletonData
+    dev = torch.device("cuda", 0)
+    model = model_from_state_dict(arch.make_synthetic_state(22)).to(dev)
+    T, R = 3, 3000
+    g = torch.Generator(device=dev).manual_seed(6)
+    fused_t = torch.randn(T, R, 72, 6, 6, generator=g, device=dev)
+    cam0_t = torch.eye(4, device=dev).repeat(T, R, 1, 1)
+    cam0_t[..., :3, 3] = torch.randn(T, R, 3, generator=g, device=dev) * 0.1
+    use_t = torch.ones(T, R, dtype=torch.bool, device=dev)
+    use_t[0] = False
+    hand_rows = (torch.arange(R, device=dev) % 2)
+    hm_m = scaled_hand_model(load_generic_hand_model(), 0.001)
+    skel = InputSkeletonData(hm_m.joint_rotation_axes.to(dev), hm_m.joint_rest_positions.to(dev))
+    model.reset_memory()
+    seq = model.head_sequence(nat.HEAD_KNOWN_SKELETON, fused_t, cam0_t, use_t, hand_rows.repeat(T, 1), skel)
+    mem_seq, _ = [x.clone() for x in model.memory_state()]
+    model.reset_memory()
+    midx = torch.arange(R, device=dev)
+    for t in range(T):
+        temporal = model.temporal_step(fused_t[t], cam0_t[t], midx, use_t[t], required_rows=R)
+        out, _ = model.regress_decode(nat.HEAD_KNOWN_SKELETON, temporal, cam0_t[t], hand_rows, skel)
+        assert torch.equal(seq.joint_angles[t], out.joint_angles), t
+        assert torch.equal(seq.wrist_xfs[t], out.wrist_xfs), t
+        assert torch.equal(seq.landmark_uncertainty_sigmas[t], out.landmark_uncertainty_sigmas), t
+    assert torch.equal(mem_seq, model.memory_state()[0])
+    model.check_status()
