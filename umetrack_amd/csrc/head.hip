@@ -333,8 +333,43 @@ __global__ void skeleton_kernel(SkelParams p, const float* axes, const float* re
   rows[((size_t)b * 36 + px) * cs + c0 + c] = v;
 }
 
+// One profile for the whole batch (umetrack_model.py:202-207; the tracker and the bench): every workgroup evaluates the 144
+// outputs once into LDS (the same fmaf chain as above) and writes them, four channels = 16 bytes per thread, to its 256
+// (sample, pixel) rows - the kernel above spent 132 multiply-adds and a 4-byte store per output of every sample.
+__global__ __launch_bounds__(256) void skeleton_broadcast_kernel(SkelParams p, const float* axes, const float* rest, int bs,
+                                                                 float* rows, int cs, int c0) {
+  __shared__ float sv[144];
+  const int o = threadIdx.x;
+  if (o < 144) {
+    const float* w = p.w + (size_t)o * 132;
+    float s = 0.f;
+    for (int j = 0; j < 22; ++j) {
+      s = fmaf(w[j * 6 + 0], axes[j * 3 + 0], s);
+      s = fmaf(w[j * 6 + 1], axes[j * 3 + 1], s);
+      s = fmaf(w[j * 6 + 2], axes[j * 3 + 2], s);
+      s = fmaf(w[j * 6 + 3], rest[j * 3 + 0], s);
+      s = fmaf(w[j * 6 + 4], rest[j * 3 + 1], s);
+      s = fmaf(w[j * 6 + 5], rest[j * 3 + 2], s);
+    }
+    const int c = o / 36;
+    const float lin = (s + p.bias[o]) * p.scale[c] + p.shift[c];
+    sv[o] = lin != lin ? lin : fmaxf(lin, 0.f);
+  }
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (sample, pixel)
+  if (row >= (int64_t)bs * 36) return;
+  const int px = (int)(row % 36);
+  *reinterpret_cast<float4*>(rows + row * cs + c0) = make_float4(sv[px], sv[36 + px], sv[72 + px], sv[108 + px]);
+}
+
 int launch_skeleton(const SkelParams& p, const float* axes, const float* rest, int n_skel, int bs, float* rows,
                     int cs, int c0, hipStream_t s) {
+  if (n_skel == 1 && cs % 4 == 0 && c0 % 4 == 0 && (reinterpret_cast<uintptr_t>(rows) & 15) == 0) {
+    hipLaunchKernelGGL(skeleton_broadcast_kernel, dim3(grid_for((int64_t)bs * 36, 256)), dim3(256), 0, s, p, axes, rest, bs, rows,
+                       cs, c0);
+    UMT_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(skeleton_kernel, dim3(grid_for((int64_t)bs * 144, 256)), dim3(256), 0, s, p, axes, rest, n_skel,
                      bs, rows, cs, c0);
   UMT_CHECK_HIP(hipGetLastError());
