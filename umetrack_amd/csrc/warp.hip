@@ -195,13 +195,16 @@ __device__ inline void load_cams(const double* __restrict__ src_cams, const doub
 
 // MODE: UMT_WARP_CV2_FIXED_POINT (float32 map + float64 re-evaluation queue), UMT_WARP_FLOAT,
 // UMT_WARP_CV2_FIXED_POINT_F64 (every pixel in float64)
-template <int MODE, bool DEPTH_CHECK = true>
+// SQ96: the crop is 96 x 96 (the network's input: three whole bands of 32 rows), so every band is full and the divisions by
+// the crop width are by a constant
+template <int MODE, bool DEPTH_CHECK = true, bool SQ96 = false>
 __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel(const uint8_t* __restrict__ src_images,
                                                             const int64_t* __restrict__ src_offset,
                                                             const int32_t* __restrict__ src_pitch,
                                                             const double* __restrict__ src_cams,
-                                                            const double* __restrict__ dst_cams, int out_h, int out_w,
-                                                            int band_h, int nbands, float* __restrict__ out) {
+                                                            const double* __restrict__ dst_cams, int out_h_, int out_w_,
+                                                            int band_h_, int nbands_, float* __restrict__ out) {
+  const int out_h = SQ96 ? 96 : out_h_, out_w = SQ96 ? 96 : out_w_, band_h = SQ96 ? IBH : band_h_, nbands = SQ96 ? 96 / IBH : nbands_;
   constexpr bool CV2 = MODE != UMT_WARP_FLOAT;
   constexpr int smode = CV2 ? UMT_WARP_CV2_FIXED_POINT : UMT_WARP_FLOAT;
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -307,7 +310,14 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
         // cubic weights sum to <= 1.25 in absolute value), 3 u relative error of each weight, and the node errors: 10 u R;
         // the row combination adds 4 roundings of sums <= 1.5625 R, the weights again and 1.25 x the column error:
         // 23.5 u R = 1.4e-6 R in all, plus the final addition (u (R + 1))
-        cell_e[tid] = 2.0f * (1.25f * eh + ev) + 1.6e-6f * __int_as_float(relmax_bits) + 0.001f;
+        // ... plus the reference's float32 cast of the coordinate (up to 2^-24 = 5.96e-8 of its magnitude), bounded for
+        // the whole band by the centre node's magnitude plus R + 1; stored as the THRESHOLD a pixel's distance from its
+        // rounded value has to stay under, 0.5 - bound (NaN for an irregular cell: every comparison with it fails), and
+        // as "nothing passes" when the band's coordinates can leave the range in which the fixed-point conversion is exact
+        const float rmax = __int_as_float(relmax_bits);
+        const float amax = fmaxf(fabsf((float)ref.x), fabsf((float)ref.y)) + rmax + 1.0f;
+        const float bound = 2.0f * (1.25f * eh + ev) + 1.6e-6f * rmax + 0.001f + 6.2e-8f * amax;
+        cell_e[tid] = amax < 960000.f ? 0.5f - bound : -1.0f;
       }
       __syncthreads();
       WSTAMP(2);
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
             t = __builtin_elementwise_fma((f32x2){wy.z, wy.z}, nb[2 * INX + c], t);
             cc[c] = __builtin_elementwise_fma((f32x2){wy.w, wy.w}, nb[3 * INX + c], t);
           }
-          const float eb = cell_e[cj * ICX + ci];
+          const float thr = cell_e[cj * ICX + ci];
           const f32x2 fr = {fxr, fyr};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -346,11 +356,9 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
             t = __builtin_elementwise_fma((f32x2){wx.w, wx.w}, cc[3], t) + fr;
             const float tx = t.x, ty = t.y;
             const float rx = rintf(tx), ry = rintf(ty);
-            const float ax = fabsf((float)irx + tx), ay = fabsf((float)iry + ty);
-            // the reference rounds float32(coordinate) * 32: that cast moves the value by up to 2^-24 = 5.96e-8 of its magnitude
-            // (bitwise: a short-circuit chain becomes four nested branches per pixel)
-            const bool ok = (int)((0.5f - fabsf(tx - rx)) > eb + 6.2e-8f * ax) & (int)((0.5f - fabsf(ty - ry)) > eb + 6.2e-8f * ay) &
-                            (int)(ax < 960000.f) & (int)(ay < 960000.f);
+            // accepted when both coordinates stay clear of a rounding boundary by the cell's bound.  The comparison is
+            // false for a NaN coordinate: fmaxf would drop a NaN operand, so the two distances are compared one by one
+            const bool ok = (int)(fabsf(tx - rx) < thr) & (int)(fabsf(ty - ry) < thr);
             sxs[i] = irx + (int)rx;                 // replaced by the queue position below when not accepted
             sys[i] = iry + (int)ry;
 #ifndef UMT_WARP_X_NOQUEUE
@@ -452,11 +460,13 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
 #pragma unroll
   for (int i = 0; i < WARP_MAX_PX; ++i) {
     const int ix = CV2 ? sxs[i] >> 5 : sxs[i], iy = CV2 ? sys[i] >> 5 : sys[i];
-    // footprint touches the image: ix in [-1, W - 1] and iy in [-1, H - 1] (selects, not branches)
-    const bool in = (int)((unsigned)(ix + 1) <= (unsigned)W) & (int)((unsigned)(iy + 1) <= (unsigned)H) &
-                    (int)(warp_pixel(tid, i) < npx);
-    bx0 = min(bx0, in ? ix : 1 << 30); bx1 = max(bx1, in ? ix + 1 : -(1 << 30));
-    by0 = min(by0, in ? iy : 1 << 30); by1 = max(by1, in ? iy + 1 : -(1 << 30));
+    // The box of ALL the band's footprints, clamped to the image below: a superset of the footprints that touch the image
+    // (a pixel whose footprint lies outside only pulls the box to the image border on its side - where, the map being
+    // continuous, the band's other pixels reach anyway; degenerate crops get a larger tile or the global-memory gather).
+    // Four min / max per pixel instead of an inside test and four selects.
+    const bool mine = SQ96 || warp_pixel(tid, i) < npx;
+    bx0 = min(bx0, mine ? ix : 1 << 30); bx1 = max(bx1, mine ? ix + 1 : -(1 << 30));
+    by0 = min(by0, mine ? iy : 1 << 30); by1 = max(by1, mine ? iy + 1 : -(1 << 30));
   }
   // workgroup bounding box of the source footprint
   for (int o = 32; o > 0; o >>= 1) {
@@ -496,22 +506,32 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
 #endif
   if (use_lds) {
     uint32_t* lds32 = reinterpret_cast<uint32_t*>(lds);
-    // flat over the tile's dwords, four independent loads in flight per thread; row = idx / tpd through a float reciprocal
-    // (exact: idx < 2^14).  Border dwords load a clamped in-rectangle address and store 0.
+    // border dwords load a clamped in-rectangle address and store 0; the unaligned form walks the tile's dwords flat, row =
+    // idx / tpd through a float reciprocal (exact: idx < 2^14)
     const float inv_tpd = 1.0f / (float)tpd;
     const int total = tpd * (th + 2);
     const uint8_t* g0 = img + (size_t)by0 * pitch + bx0 - mis;
     if (aligned) {
+      // a wave per tile row (rows dealt round-robin to the four waves), a lane per dword column: everything about the column
+      // (its byte offset, the mask that cuts the partial dwords at the rectangle's ends and the border columns to zero) is
+      // computed once, the row's base address is scalar, and a row costs a load, an AND and an LDS store per lane - the
+      // flat index form spent ~40 vector instructions per dword on its row / column split, clamps and masks
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
+      for (int c0 = 0; c0 < tpd; c0 += 64) {                   // one trip unless the rectangle is wider than 248 pixels
+        const int c = c0 + ln;
+        const int b0 = 4 * (min(max(c, 1), tpd - 2) - 1);      // byte offset of this dword from the row's aligned start
+        const int start = mis - b0, end = mis + tw - b0;       // rectangle bytes are [start, end) of the dword
+        uint32_t mask = (c >= 1 && c < tpd - 1) ? 0xffffffffu : 0u;
+        if (start > 0) mask &= 0xffffffffu << (8 * start);
+        if (end < 4) mask &= (1u << (8 * end)) - 1u;
+        const bool col = c < tpd;
 #pragma unroll 4
-      for (int idx = tid; idx < total; idx += WARP_THREADS) {
-        const int row = (int)(((float)idx + 0.5f) * inv_tpd), c = idx - row * tpd;
-        const bool data = row >= 1 && row <= th && c >= 1 && c < tpd - 1;
-        const int b0 = 4 * (min(max(c, 1), tpd - 2) - 1);     // byte offset of this dword from the row's aligned start
-        uint32_t v = *reinterpret_cast<const uint32_t*>(g0 + (size_t)(min(max(row, 1), th) - 1) * pitch + b0);
-        const int start = mis - b0, end = mis + tw - b0;      // rectangle bytes are [start, end) of the dword
-        if (start > 0) v &= 0xffffffffu << (8 * start);
-        if (end < 4) v &= (1u << (8 * end)) - 1u;
-        lds32[idx] = data ? v : 0u;
+        for (int row = wv; row < th + 2; row += WARP_THREADS / 64) {
+          const uint8_t* grow = g0 + (size_t)(min(max(row, 1), th) - 1) * pitch;     // scalar
+          const uint32_t v = *reinterpret_cast<const uint32_t*>(grow + b0);
+          const uint32_t rmask = (row >= 1 && row <= th) ? mask : 0u;                 // the zero rows above and below
+          if (col) lds32[row * tpd + c] = v & rmask;
+        }
       }
     } else {
       for (int idx = tid; idx < total; idx += WARP_THREADS) {
@@ -617,7 +637,8 @@ extern "C" int umt_warp_crops(const uint8_t* src_images, const int64_t* src_offs
   UMT_REQUIRE(src_images && src_offset && src_pitch && src_cams && dst_cams && out, UMT_ERR_INVALID, "warp: null pointer");
   // depth_check=False (tracker.py:59, never used by the reference's own callers) runs every pixel in float64
   if (!depth_check && mode == UMT_WARP_CV2_FIXED_POINT) mode = UMT_WARP_CV2_FIXED_POINT_F64;
-  auto kern = mode == UMT_WARP_CV2_FIXED_POINT ? warp_kernel<UMT_WARP_CV2_FIXED_POINT>
+  const bool sq96 = out_h == 96 && out_w == 96;
+  auto kern = mode == UMT_WARP_CV2_FIXED_POINT ? (sq96 ? warp_kernel<UMT_WARP_CV2_FIXED_POINT, true, true> : warp_kernel<UMT_WARP_CV2_FIXED_POINT>)
               : mode == UMT_WARP_FLOAT         ? (depth_check ? warp_kernel<UMT_WARP_FLOAT> : warp_kernel<UMT_WARP_FLOAT, false>)
               : depth_check                    ? warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64>
                                                : warp_kernel<UMT_WARP_CV2_FIXED_POINT_F64, false>;
