@@ -525,12 +525,20 @@ __global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel
         if (start > 0) mask &= 0xffffffffu << (8 * start);
         if (end < 4) mask &= (1u << (8 * end)) - 1u;
         const bool col = c < tpd;
-#pragma unroll 4
-        for (int row = wv; row < th + 2; row += WARP_THREADS / 64) {
-          const uint8_t* grow = g0 + (size_t)(min(max(row, 1), th) - 1) * pitch;     // scalar
-          const uint32_t v = *reinterpret_cast<const uint32_t*>(grow + b0);
-          const uint32_t rmask = (row >= 1 && row <= th) ? mask : 0u;                 // the zero rows above and below
-          if (col) lds32[row * tpd + c] = v & rmask;
+        constexpr int NW = WARP_THREADS / 64, RB = 16;          // a wave's rows in batches of RB loads in flight
+        for (int r0 = wv; r0 < th + 2; r0 += NW * RB) {
+          uint32_t v[RB];
+#pragma unroll
+          for (int k = 0; k < RB; ++k) {                         // rows past the tile re-read its last row (not stored)
+            const uint8_t* grow = g0 + (size_t)(min(max(r0 + NW * k, 1), th) - 1) * pitch;     // scalar
+            v[k] = *reinterpret_cast<const uint32_t*>(grow + b0);
+          }
+#pragma unroll
+          for (int k = 0; k < RB; ++k) {
+            const int row = r0 + NW * k;
+            const uint32_t rmask = (row >= 1 && row <= th) ? mask : 0u;               // the zero rows above and below
+            if (col && row < th + 2) lds32[row * tpd + c] = v[k] & rmask;
+          }
         }
       }
     } else {
