@@ -31,14 +31,16 @@ __device__ unsigned long long g_wstamp[16];
 #define WSTAMP(i) do {} while (0)
 #endif
 
-constexpr int WARP_THREADS = 256;                // one workgroup = a band of rows of one crop; 4-5 bands share a CU, so a band's
+constexpr int WARP_THREADS = 256;                // one workgroup = a band of rows of one crop; 4-6 bands share a CU, so a band's
                                                  // barrier-separated phases (latency chains) overlap with other bands' phases
 constexpr int WARP_MAX_PX = 12;                 // pixels per thread, as 3 groups of 4 consecutive pixels
 constexpr int WARP_BAND_PX = WARP_MAX_PX * WARP_THREADS;   // 3072 pixels per band: 32 rows of a 96-wide crop
 constexpr int WARP_LDS_BYTES = 24 * 1024;       // source rectangle budget of a band
 #ifndef WARP_WAVES_PER_SIMD
-#define WARP_WAVES_PER_SIMD 4
-#endif
+#define WARP_WAVES_PER_SIMD 6                    // of the interpolated-map kernel: six bands per CU is what its 25.7 KB of LDS allows.
+#endif                                           // Measured per 16 384 crops: 4 -> 1.109 ms (123 registers), 5 -> 1.034 (96, 15
+                                                 // spilled), 6 -> 1.022 (80, 40 spilled): the phases' latency chains need the company
+constexpr int WARP_WAVES_F64 = 4;                // the all-float64 kernels (check modes) keep their registers
 constexpr int WARP_QCAP = 1024;                 // float64 re-evaluation queue window (10 KB; the rectangle later reuses the space)
 
 struct SrcCam {
@@ -198,7 +200,7 @@ __device__ inline void load_cams(const double* __restrict__ src_cams, const doub
 // SQ96: the crop is 96 x 96 (the network's input: three whole bands of 32 rows), so every band is full and the divisions by
 // the crop width are by a constant
 template <int MODE, bool DEPTH_CHECK = true, bool SQ96 = false>
-__global__ __launch_bounds__(WARP_THREADS, WARP_WAVES_PER_SIMD) void warp_kernel(const uint8_t* __restrict__ src_images,
+__global__ __launch_bounds__(WARP_THREADS, MODE == UMT_WARP_CV2_FIXED_POINT ? WARP_WAVES_PER_SIMD : WARP_WAVES_F64) void warp_kernel(const uint8_t* __restrict__ src_images,
                                                             const int64_t* __restrict__ src_offset,
                                                             const int32_t* __restrict__ src_pitch,
                                                             const double* __restrict__ src_cams,
